@@ -1,0 +1,109 @@
+// capi.cpp -- C entry points over the host scene API, for callers that cannot use the
+// C++ classes directly (the Python harness in tests/ and bench.py).  They only build
+// worlds, cameras and recipes; every per-ray call goes to rtiow_hip.h with the
+// rt_scene handle obtained here.
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "recipe.hpp"
+#include "rtiow.hpp"
+
+using namespace rtiow;
+
+namespace {
+thread_local std::string g_error;
+
+template <class F> int guarded(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (std::exception const& e) {
+        g_error = e.what();
+    } catch (char const* e) {
+        g_error = e;
+    } catch (...) {
+        g_error = "unknown error";
+    }
+    return 1;
+}
+}  // namespace
+
+struct rth_world {
+    std::mt19937 mt{0};                       // the generator the materials are bound to
+    std::unique_ptr<object const> world;
+    std::unique_ptr<device_scene> scene;
+    std::unique_ptr<scene_flattener> flat;   // tables of a world that was not uploaded
+    rt_scene_desc desc{};
+};
+
+extern "C" {
+
+const char* rth_last_error(void) { return g_error.c_str(); }
+
+// kind: "two_perlin", "book1" (static spheres, grey ground), "book2" (moving spheres,
+// chequer ground: main.cpp:61-99 as written), "stress" (n spheres)
+int rth_generate(const char* kind, uint32_t seed, int n, const char* path) {
+    return guarded([&] {
+        std::string const k = kind ? kind : "";
+        recipe rc;
+        if (k == "two_perlin") rc = recipe_two_perlin_spheres();
+        else if (k == "book1") rc = recipe_random_spheres(seed, false, false);
+        else if (k == "book2") rc = recipe_random_spheres(seed, true, true);
+        else if (k == "stress") rc = recipe_stress(seed, n);
+        else throw std::runtime_error("unknown scene kind '" + k + "'");
+        rc.save(path);
+    });
+}
+
+// Builds the recipe's world through the scene API, flattens it and uploads it to `device`.
+int rth_world_load(const char* recipe_path, int device, rth_world** out) {
+    *out = nullptr;
+    return guarded([&] {
+        auto w = std::make_unique<rth_world>();
+        recipe const rc = recipe::load(recipe_path);
+        w->world = rc.instantiate(w->mt);
+        w->scene = std::make_unique<device_scene>(*w->world, device);
+        w->desc = w->scene->tables().desc();
+        *out = w.release();
+    });
+}
+
+void rth_world_free(rth_world* w) { delete w; }
+rt_scene* rth_world_scene(rth_world* w) { return w->scene->get(); }
+const rt_scene_desc* rth_world_desc(rth_world* w) { return &w->desc; }
+
+// Flattens a recipe's world without touching a GPU: tables only (for host-side checks).
+int rth_world_tables(const char* recipe_path, rth_world** out) {
+    *out = nullptr;
+    return guarded([&] {
+        auto w = std::make_unique<rth_world>();
+        recipe const rc = recipe::load(recipe_path);
+        w->world = rc.instantiate(w->mt);
+        w->flat = std::make_unique<scene_flattener>();
+        w->world->flatten_items(*w->flat);
+        w->desc = w->flat->desc();
+        *out = w.release();
+    });
+}
+
+// cam: from(3) at(3) up(3) vfov aspect aperture focus_dist t0 t1  (camera.cpp:25-36)
+int rth_camera(const double* cam, rt_camera* out) {
+    return guarded([&] {
+        std::mt19937 mt;
+        camera const c{mt, vec3{cam[0], cam[1], cam[2]}, vec3{cam[3], cam[4], cam[5]}, vec3{cam[6], cam[7], cam[8]},
+                       cam[9], cam[10], cam[11], cam[12], cam[13], cam[14]};
+        *out = c.describe();
+    });
+}
+
+void rth_perlin_tables(double* ranfloat, uint8_t* px, uint8_t* py, uint8_t* pz) {
+    std::memcpy(ranfloat, perlin::ranfloat.data(), 256 * sizeof(double));
+    std::memcpy(px, perlin::perm_x.data(), 256);
+    std::memcpy(py, perlin::perm_y.data(), 256);
+    std::memcpy(pz, perlin::perm_z.data(), 256);
+}
+
+}  // extern "C"

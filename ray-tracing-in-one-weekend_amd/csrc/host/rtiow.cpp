@@ -1,0 +1,588 @@
+// rtiow.cpp -- host-side scene API: value types, bounding boxes, the BVH build, the
+// camera basis, flattening into the C ABI's tables, and the thin calls into the GPU
+// library for everything on the per-ray path.  Reference citations are file:line under
+// c++/ of hgiddens/ray-tracing-in-one-weekend.
+#include "rtiow.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace rtiow {
+
+namespace {
+
+[[noreturn]] void device_failure(char const* what) {
+    throw std::runtime_error(std::string(what) + ": " + rt_last_error());
+}
+
+rt_ray to_abi(ray const& r) {
+    return {{r.origin().x(), r.origin().y(), r.origin().z()}, {r.direction().x(), r.direction().y(), r.direction().z()}, r.time()};
+}
+
+ray from_abi(rt_ray const& r) {
+    return {vec3{r.origin[0], r.origin[1], r.origin[2]}, vec3{r.direction[0], r.direction[1], r.direction[2]}, r.time};
+}
+
+// Uniforms the GPU call will consume, taken from a COPY of the shared generator as
+// std::uniform_real_distribution would take them (two 32-bit draws per value).
+std::vector<double> peek_uniforms(std::mt19937 const& mt, size_t k) {
+    std::mt19937 copy = mt;
+    std::vector<double> tape(k);
+    for (double& u : tape) u = std::generate_canonical<double, 53>(copy);
+    return tape;
+}
+
+void advance(std::mt19937& mt, int used) { mt.discard(2ull * (unsigned long long)used); }
+
+}  // namespace
+
+// ---------------------------------------------------------------- value types ----
+// vec3.cpp:16-74: component-wise, scalar division divides each component
+vec3 vec3::cross(vec3 that) const {
+    return {y() * that.z() - z() * that.y(), -(x() * that.z() - z() * that.x()), x() * that.y() - y() * that.x()};
+}
+double vec3::dot(vec3 that) const { return x() * that.x() + y() * that.y() + z() * that.z(); }
+double vec3::length() const { return std::sqrt(squared_length()); }
+double vec3::squared_length() const { return x() * x() + y() * y() + z() * z(); }
+vec3 vec3::unit_vector() const { return *this / length(); }
+vec3 operator+(vec3 a, vec3 b) { return {a.x() + b.x(), a.y() + b.y(), a.z() + b.z()}; }
+vec3 operator-(vec3 a, vec3 b) { return {a.x() - b.x(), a.y() - b.y(), a.z() - b.z()}; }
+vec3 operator*(vec3 v, double d) { return {v.x() * d, v.y() * d, v.z() * d}; }
+vec3 operator*(double d, vec3 v) { return {v.x() * d, v.y() * d, v.z() * d}; }
+vec3 operator/(vec3 v, double d) { return {v.x() / d, v.y() / d, v.z() / d}; }
+
+// colour.cpp:19-46
+colour colour::gamma2() const { return {std::sqrt(red()), std::sqrt(green()), std::sqrt(blue())}; }
+colour operator+(colour a, colour b) { return {a.red() + b.red(), a.green() + b.green(), a.blue() + b.blue()}; }
+colour operator*(colour c, double d) { return {c.red() * d, c.green() * d, c.blue() * d}; }
+colour operator*(double d, colour c) { return {c.red() * d, c.green() * d, c.blue() * d}; }
+
+// aabb.cpp:59-64
+aabb aabb::surrounding_box(aabb box0, aabb box1) {
+    vec3 const small{std::fmin(box0.min().x(), box1.min().x()), std::fmin(box0.min().y(), box1.min().y()),
+                     std::fmin(box0.min().z(), box1.min().z())};
+    vec3 const big{std::fmax(box0.max().x(), box1.max().x()), std::fmax(box0.max().y(), box1.max().y()),
+                   std::fmax(box0.max().z(), box1.max().z())};
+    return aabb(small, big);
+}
+
+bool aabb::hit(ray const& r, double tmin, double tmax) const {
+    double const box[6] = {_min.x(), _min.y(), _min.z(), _max.x(), _max.y(), _max.z()};
+    rt_ray const rr = to_abi(r);
+    uint8_t out = 0;
+    if (rt_aabb_hit_batch(0, box, &rr, &tmin, &tmax, 1, &out)) device_failure("aabb::hit");
+    return out != 0;
+}
+
+// ------------------------------------------------------------------ flattening ----
+rt_scene_desc scene_flattener::desc() const {
+    rt_scene_desc d{};
+    d.textures = textures.data(); d.n_textures = (uint32_t)textures.size();
+    d.materials = materials.data(); d.n_materials = (uint32_t)materials.size();
+    d.prims = prims.data(); d.n_prims = (uint32_t)prims.size();
+    d.nodes = nodes.data(); d.n_nodes = (uint32_t)nodes.size();
+    d.items = items.data(); d.n_items = (uint32_t)items.size();
+    d.perlin_ranfloat = perlin::ranfloat.data();
+    d.perlin_perm_x = perlin::perm_x.data();
+    d.perlin_perm_y = perlin::perm_y.data();
+    d.perlin_perm_z = perlin::perm_z.data();
+    return d;
+}
+
+device_scene::device_scene(object const& world, int device) {
+    world.flatten_items(flat);
+    rt_scene_desc const d = flat.desc();
+    if (rt_scene_create(&d, device, &handle)) device_failure("device_scene");
+}
+
+device_scene::~device_scene() { rt_scene_destroy(handle); }
+
+// -------------------------------------------------------------------- textures ----
+texture::texture() = default;
+texture::~texture() = default;
+
+uint32_t constant_texture::flatten(scene_flattener& out) const {
+    rt_texture_desc t{};
+    t.kind = RT_TEX_CONSTANT;
+    t.colour[0] = c.red(); t.colour[1] = c.green(); t.colour[2] = c.blue();
+    out.textures.push_back(t);
+    return (uint32_t)out.textures.size() - 1;
+}
+
+chequer_texture::chequer_texture(std::unique_ptr<texture const> even, std::unique_ptr<texture const> odd)
+    : even(std::move(even)), odd(std::move(odd)) {}
+
+uint32_t chequer_texture::flatten(scene_flattener& out) const {
+    rt_texture_desc t{};
+    t.kind = RT_TEX_CHEQUER;
+    t.even = even->flatten(out);
+    t.odd = odd->flatten(out);
+    out.textures.push_back(t);
+    return (uint32_t)out.textures.size() - 1;
+}
+
+uint32_t perlin_texture::flatten(scene_flattener& out) const {
+    rt_texture_desc t{};
+    t.kind = RT_TEX_PERLIN;
+    out.textures.push_back(t);
+    return (uint32_t)out.textures.size() - 1;
+}
+
+namespace {
+
+// A unit sphere carrying one material: the smallest scene through which a lone texture
+// or material can be evaluated on the GPU.
+class probe_object final : public object {
+    material const& m;
+public:
+    explicit probe_object(material const& m) : m(m) {}
+    std::optional<aabb> bounding_box(double, double) const override { return aabb(vec3{-1, -1, -1}, vec3{1, 1, 1}); }
+    int32_t flatten_child(scene_flattener& out) const override {
+        rt_prim_desc p{};
+        p.kind = RT_PRIM_SPHERE;
+        p.material = m.flatten(out);
+        p.radius = 1; p.time1 = 1;
+        out.prims.push_back(p);
+        out.material_of_prim.push_back(&m);
+        return ~(int32_t)(out.prims.size() - 1);
+    }
+};
+
+class probe_material final : public material {
+    texture const& t;
+    static std::mt19937 unused;
+public:
+    explicit probe_material(texture const& t) : material(unused), t(t) {}
+    uint32_t flatten(scene_flattener& out) const override {
+        rt_material_desc m{};
+        m.kind = RT_MAT_LAMBERTIAN;
+        m.texture = t.flatten(out);
+        out.materials.push_back(m);
+        return (uint32_t)out.materials.size() - 1;
+    }
+};
+std::mt19937 probe_material::unused;
+
+}  // namespace
+
+colour texture::value(double, double, vec3 const& p) const {
+    if (!probe) {
+        probe_material pm(*this);
+        probe_object po(pm);
+        probe = std::make_unique<device_scene>(po);
+    }
+    double const in[3] = {p.x(), p.y(), p.z()};
+    double out[3];
+    // the texture itself is the last entry of the probe's table
+    uint32_t const self = (uint32_t)probe->tables().textures.size() - 1;
+    if (rt_texture_batch(probe->get(), self, in, 1, out)) device_failure("texture::value");
+    return {out[0], out[1], out[2]};
+}
+
+// perlin.cpp:8-31,50-53 with glibc's drand48() in its default state written out:
+// X <- (0x5DEECE66D X + 0xB) mod 2^48 from X = 0 (glibc zero-initialises the state),
+// value X / 2^48.
+namespace {
+struct lcg48 {
+    uint64_t x = 0;
+    double next() {
+        x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;
+        return (double)x / 281474976710656.0;
+    }
+};
+lcg48& perlin_source() { static lcg48 g; return g; }
+
+std::vector<double> perlin_generate() {
+    std::vector<double> p(256);
+    for (double& v : p) v = perlin_source().next();
+    return p;
+}
+
+std::vector<uint8_t> perlin_generate_perm() {
+    std::vector<uint8_t> p(256);
+    for (size_t i = 0; i < p.size(); ++i) p[i] = (uint8_t)i;
+    for (size_t i = p.size() - 1; i > 0; --i) {
+        size_t const target = (size_t)int(perlin_source().next() * (i + 1));
+        std::swap(p[i], p[target]);
+    }
+    return p;
+}
+}  // namespace
+
+std::vector<double> const perlin::ranfloat = perlin_generate();
+std::vector<uint8_t> const perlin::perm_x = perlin_generate_perm();
+std::vector<uint8_t> const perlin::perm_y = perlin_generate_perm();
+std::vector<uint8_t> const perlin::perm_z = perlin_generate_perm();
+
+double perlin::noise(vec3 const& p) const { return perlin_texture{}.value(0, 0, p).red(); }
+
+// ------------------------------------------------------------------- materials ----
+material::material(std::mt19937& mt) : mt(mt) {}
+material::~material() = default;
+
+std::optional<scatter_record> material::scatter(ray const& r, hit_record const& hit) const {
+    if (!probe) {
+        probe_object po(*this);
+        probe = std::make_unique<device_scene>(po);
+    }
+    rt_ray const in = to_abi(r);
+    rt_hit h{};
+    h.hit = 1; h.prim = 0; h.t = hit.t;
+    h.p[0] = hit.p.x(); h.p[1] = hit.p.y(); h.p[2] = hit.p.z();
+    h.normal[0] = hit.normal.x(); h.normal[1] = hit.normal.y(); h.normal[2] = hit.normal.z();
+    int32_t const prim = 0;
+    for (uint32_t k = 64;; k *= 4) {
+        std::vector<double> const tape = peek_uniforms(mt, k);
+        uint8_t scattered = 0;
+        double att[3];
+        rt_ray out;
+        int32_t used = 0;
+        int const rc = rt_scatter_batch(probe->get(), &prim, &in, &h, tape.data(), k, 1, &scattered, att, &out, &used);
+        if (rc == RT_E_TAPE && k < (1u << 20)) continue;
+        if (rc) device_failure("material::scatter");
+        advance(mt, used);
+        if (!scattered) return std::nullopt;
+        return scatter_record{vec3{att[0], att[1], att[2]}, from_abi(out)};
+    }
+}
+
+lambertian::lambertian(std::mt19937& mt, std::unique_ptr<texture const> texture) : material(mt), t(std::move(texture)) {}
+
+uint32_t lambertian::flatten(scene_flattener& out) const {
+    rt_material_desc m{};
+    m.kind = RT_MAT_LAMBERTIAN;
+    m.texture = t->flatten(out);
+    out.materials.push_back(m);
+    return (uint32_t)out.materials.size() - 1;
+}
+
+metal::metal(std::mt19937& mt, vec3 const albedo, double const fuzziness) : material(mt), albedo(albedo), fuzziness(fuzziness) {
+    assert(fuzziness <= 1);
+}
+
+uint32_t metal::flatten(scene_flattener& out) const {
+    rt_material_desc m{};
+    m.kind = RT_MAT_METAL;
+    m.albedo[0] = albedo.x(); m.albedo[1] = albedo.y(); m.albedo[2] = albedo.z();
+    m.fuzziness = fuzziness;
+    out.materials.push_back(m);
+    return (uint32_t)out.materials.size() - 1;
+}
+
+dielectric::dielectric(std::mt19937& mt, double const refractive_index) : material(mt), refractive_index(refractive_index) {
+    assert(refractive_index >= 0);
+}
+
+uint32_t dielectric::flatten(scene_flattener& out) const {
+    rt_material_desc m{};
+    m.kind = RT_MAT_DIELECTRIC;
+    m.refractive_index = refractive_index;
+    out.materials.push_back(m);
+    return (uint32_t)out.materials.size() - 1;
+}
+
+// --------------------------------------------------------------------- objects ----
+object::object() = default;
+object::~object() = default;
+
+void object::flatten_items(scene_flattener& out) const {
+    int32_t const ref = flatten_child(out);
+    rt_item_desc it{};
+    it.is_bvh = ref >= 0;
+    it.index = ref >= 0 ? ref : ~ref;
+    out.items.push_back(it);
+}
+
+std::optional<hit_record> object::hit(ray const& r, double t_min, double t_max) const {
+    if (!self_scene) self_scene = std::make_unique<device_scene>(*this);
+    rt_ray const in = to_abi(r);
+    rt_hit h;
+    if (rt_trace_batch(self_scene->get(), &in, 1, t_min, t_max, &h)) device_failure("object::hit");
+    if (!h.hit) return std::nullopt;
+    return hit_record{h.t, vec3{h.p[0], h.p[1], h.p[2]}, vec3{h.normal[0], h.normal[1], h.normal[2]},
+                      self_scene->tables().material_of_prim[(size_t)h.prim]};
+}
+
+sphere::sphere(vec3 const centre, double radius, std::unique_ptr<material const> mat)
+    : centre(centre), radius(radius), mat(std::move(mat)) {}
+
+// sphere.cpp:47-50
+std::optional<aabb> sphere::bounding_box(double, double) const {
+    vec3 const rv = vec3(radius, radius, radius);
+    return aabb(centre - rv, centre + rv);
+}
+
+int32_t sphere::flatten_child(scene_flattener& out) const {
+    rt_prim_desc p{};
+    p.kind = RT_PRIM_SPHERE;
+    p.material = mat->flatten(out);
+    p.centre0[0] = p.centre1[0] = centre.x();
+    p.centre0[1] = p.centre1[1] = centre.y();
+    p.centre0[2] = p.centre1[2] = centre.z();
+    p.time0 = 0; p.time1 = 1; p.radius = radius;
+    out.prims.push_back(p);
+    out.material_of_prim.push_back(mat.get());
+    return ~(int32_t)(out.prims.size() - 1);
+}
+
+moving_sphere::moving_sphere(vec3 const centre0, vec3 const centre1, double const time0, double const time1,
+                             double radius, std::unique_ptr<material const> mat)
+    : centre0(centre0), centre1(centre1), time0(time0), time1(time1), radius(radius), mat(std::move(mat)) {}
+
+// moving_sphere.cpp:3-5
+vec3 moving_sphere::centre(double const time) const {
+    return centre0 + ((time - time0) / (time1 - time0)) * (centre1 - centre0);
+}
+
+// moving_sphere.cpp:51-60: the second box's far corner is taken at the START centre,
+// exactly as the reference writes it; the tree the GPU walks must cull what the
+// reference's tree culls.
+std::optional<aabb> moving_sphere::bounding_box(double const t0, double const t1) const {
+    vec3 const rv = vec3(radius, radius, radius), c0 = centre(t0), c1 = centre(t1);
+    aabb const box0{c0 - rv, c0 + rv}, box1{c1 - rv, c0 + rv};
+    return aabb::surrounding_box(box0, box1);
+}
+
+int32_t moving_sphere::flatten_child(scene_flattener& out) const {
+    rt_prim_desc p{};
+    p.kind = RT_PRIM_MOVING_SPHERE;
+    p.material = mat->flatten(out);
+    p.centre0[0] = centre0.x(); p.centre0[1] = centre0.y(); p.centre0[2] = centre0.z();
+    p.centre1[0] = centre1.x(); p.centre1[1] = centre1.y(); p.centre1[2] = centre1.z();
+    p.time0 = time0; p.time1 = time1; p.radius = radius;
+    out.prims.push_back(p);
+    out.material_of_prim.push_back(mat.get());
+    return ~(int32_t)(out.prims.size() - 1);
+}
+
+object_list::object_list(std::unique_ptr<object const> object) { objects.push_back(std::move(object)); }
+object_list::object_list(std::vector<std::unique_ptr<object const>> objects) : objects(std::move(objects)) {}
+
+// object_list.cpp:28-48
+std::optional<aabb> object_list::bounding_box(double t0, double t1) const {
+    auto it = objects.begin();
+    if (it == objects.end()) return std::nullopt;
+    std::optional<aabb> result = (**it).bounding_box(t0, t1);
+    if (!result) return std::nullopt;
+    while (++it != objects.end()) {
+        std::optional<aabb> next = (**it).bounding_box(t0, t1);
+        if (!next) return std::nullopt;
+        *result = aabb::surrounding_box(*result, *next);
+    }
+    return result;
+}
+
+int32_t object_list::flatten_child(scene_flattener&) const {
+    throw std::runtime_error("object_list below a bvh_node is not supported by the GPU scene layout");
+}
+
+// A list scans its members in order, each seeing the interval narrowed by the ones
+// before (object_list.cpp:15-23); a list inside a list therefore scans like its
+// members written out in place.
+void object_list::flatten_items(scene_flattener& out) const {
+    for (auto const& o : objects) o->flatten_items(out);
+}
+
+std::uniform_int_distribution<int> bvh_node::dist{0, 2};
+
+// bvh_node.cpp:8-50
+bvh_node::bvh_node(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double const t0, double const t1) {
+    int const axis = dist(mt);
+    std::ranges::sort(objects, [axis, t0, t1](std::unique_ptr<object const> const& l, std::unique_ptr<object const> const& r) -> bool {
+        std::optional<aabb> box_left = l != nullptr ? l->bounding_box(t0, t1) : std::nullopt,
+                            box_right = r != nullptr ? r->bounding_box(t0, t1) : std::nullopt;
+        if (!box_left || !box_right) throw "no bounding box in bvh_node constructor";
+        switch (axis) {
+        case 0: return box_left->min().x() < box_right->min().x();
+        case 1: return box_left->min().y() < box_right->min().y();
+        case 2: return box_left->min().z() < box_right->min().z();
+        default: throw "something has gone terribly wrong";
+        }
+    });
+
+    assert(objects.size() > 0);
+    if (objects.size() == 1) {
+        left = right = std::shared_ptr<object const>(std::move(objects[0]));
+    } else if (objects.size() == 2) {
+        left = std::move(objects[0]);
+        right = std::move(objects[1]);
+    } else {
+        left = std::make_unique<bvh_node const>(mt, objects.subspan(0, objects.size() / 2), t0, t1);
+        right = std::make_unique<bvh_node const>(mt, objects.subspan(objects.size() / 2), t0, t1);
+    }
+
+    std::optional<aabb> const box_left = left->bounding_box(t0, t1), box_right = right->bounding_box(t0, t1);
+    if (!box_left || !box_right) throw "no bounding box in bvh_node constructor";
+    box = aabb::surrounding_box(*box_left, *box_right);
+}
+
+std::optional<aabb> bvh_node::bounding_box(double, double) const { return box; }
+
+// Nodes are numbered in pre-order: a node, its whole left subtree, its right subtree.
+int32_t bvh_node::flatten_child(scene_flattener& out) const {
+    int32_t const me = (int32_t)out.nodes.size();
+    out.nodes.emplace_back();
+    int32_t const l = left->flatten_child(out);
+    int32_t const r = (right == left) ? l : right->flatten_child(out);
+    rt_node_desc n{};
+    n.box_min[0] = box->min().x(); n.box_min[1] = box->min().y(); n.box_min[2] = box->min().z();
+    n.box_max[0] = box->max().x(); n.box_max[1] = box->max().y(); n.box_max[2] = box->max().z();
+    n.left = l; n.right = r;
+    out.nodes[(size_t)me] = n;
+    return me;
+}
+
+// ---------------------------------------------------------------------- camera ----
+std::uniform_real_distribution<double> camera::dist{-1, 1};
+
+namespace {
+// camera.cpp:6-14
+double half_height(double const vfov) {
+    double const theta = vfov * M_PI / 180;
+    return std::tan(theta / 2);
+}
+double half_width(double const vfov, double const aspect) { return aspect * half_height(vfov); }
+}  // namespace
+
+// camera.cpp:25-36
+camera::camera(std::mt19937& mt, vec3 const from, vec3 const at, vec3 const up, double const vfov, double const aspect,
+               double const aperture, double const focus_dist, double const t0, double const t1)
+    : origin{from},
+      w{(from - at).unit_vector()},
+      u{up.cross(w).unit_vector()},
+      v{w.cross(u)},
+      lower_left_corner{from - half_width(vfov, aspect) * focus_dist * u - half_height(vfov) * focus_dist * v - focus_dist * w},
+      horizontal{2 * half_width(vfov, aspect) * focus_dist * u},
+      vertical{2 * half_height(vfov) * focus_dist * v},
+      lens_radius{aperture / 2},
+      t0(t0),
+      t1(t1),
+      mt(mt) {}
+
+rt_camera camera::describe() const {
+    rt_camera c{};
+    auto put = [](double* dst, vec3 const& s) { dst[0] = s.x(); dst[1] = s.y(); dst[2] = s.z(); };
+    put(c.origin, origin); put(c.u, u); put(c.v, v); put(c.w, w);
+    put(c.lower_left_corner, lower_left_corner); put(c.horizontal, horizontal); put(c.vertical, vertical);
+    c.lens_radius = lens_radius; c.time0 = t0; c.time1 = t1;
+    return c;
+}
+
+ray camera::get_ray(double const s, double const t) const {
+    rt_camera const c = describe();
+    double const st[2] = {s, t};
+    for (uint32_t k = 64;; k *= 4) {
+        std::vector<double> const tape = peek_uniforms(mt, k);
+        rt_ray out;
+        int32_t used = 0;
+        int const rc = rt_camera_batch(0, &c, st, tape.data(), k, 1, &out, &used);
+        if (rc == RT_E_TAPE && k < (1u << 20)) continue;
+        if (rc) device_failure("camera::get_ray");
+        advance(mt, used);
+        return from_abi(out);
+    }
+}
+
+// supersampler.cpp:3-19
+supersampler::supersampler() : count(0), r(0), g(0), b(0) {}
+
+void supersampler::add_sample(colour const colour) {
+    ++count;
+    r += colour.red(); g += colour.green(); b += colour.blue();
+}
+
+colour supersampler::value() const {
+    if (count == 0) return colour{0};
+    return {r / count, g / count, b / count};
+}
+
+// ----------------------------------------------------------------------- frame ----
+frame render(device_scene const& scene, camera const& cam, render_options const& opt) {
+    frame f;
+    f.nx = opt.nx; f.ny = opt.ny; f.ns = opt.ns;
+    f.sums.assign((size_t)opt.nx * opt.ny * 3, 0.0f);
+    rt_camera const c = cam.describe();
+    rt_render_params p{};
+    p.nx = (uint32_t)opt.nx; p.ny = (uint32_t)opt.ny;
+    p.sample_begin = 0; p.sample_end = (uint32_t)opt.ns;
+    p.max_depth = (uint32_t)opt.max_depth;
+    p.accum_type = RT_ACCUM_F32;
+    p.t_min = opt.t_min;
+    p.seed = opt.seed;
+    if (rt_render_host(scene.get(), &c, &p, f.sums.data(), &f.stats)) device_failure("render");
+    return f;
+}
+
+frame render(object const& world, camera const& cam, render_options const& opt) {
+    device_scene scene(world, opt.device);
+    return render(scene, cam, opt);
+}
+
+colour frame::pixel(int i, int row) const {
+    float const* s = &sums[((size_t)row * nx + i) * 3];
+    if (ns == 0) return colour{0};
+    return colour{(double)s[0] / ns, (double)s[1] / ns, (double)s[2] / ns}.gamma2();
+}
+
+// main.cpp:26-28,145-150
+void frame::write_ppm(std::FILE* out) const {
+    std::fprintf(out, "P3\n%d %d\n255\n", nx, ny);
+    for (int row = 0; row < ny; ++row)
+        for (int i = 0; i < nx; ++i) {
+            colour const c = pixel(i, row);
+            std::fprintf(out, "%d %d %d\n", int(255.99 * c.red()), int(255.99 * c.green()), int(255.99 * c.blue()));
+        }
+}
+
+// ------------------------------------------------------------- scene builders ----
+// main.cpp:52-59
+object_list two_perlin_spheres(std::mt19937& mt) {
+    std::vector<std::unique_ptr<object const>> objects;
+    objects.push_back(std::make_unique<sphere const>(vec3{0, -1000, 0}, 1000, std::make_unique<lambertian const>(mt, std::make_unique<perlin_texture const>())));
+    objects.push_back(std::make_unique<sphere const>(vec3{0, 2, 0}, 2, std::make_unique<lambertian const>(mt, std::make_unique<perlin_texture const>())));
+    return object_list(std::move(objects));
+}
+
+// main.cpp:61-99, with every draw bound to a named value so the order is the textual one
+bvh_node build_world(std::mt19937& mt) {
+    std::vector<std::unique_ptr<object const>> objects;
+    objects.reserve(500);
+    auto chequer = std::make_unique<chequer_texture const>(std::make_unique<constant_texture const>(colour{0.2, 0.3, 0.1}),
+                                                           std::make_unique<constant_texture const>(colour{0.9, 0.9, 0.9}));
+    objects.push_back(std::make_unique<sphere const>(vec3{0, -1000, -1}, 1000, std::make_unique<lambertian const>(mt, std::move(chequer))));
+    objects.push_back(std::make_unique<sphere const>(vec3{0, 1, 0}, 1, std::make_unique<dielectric const>(mt, 1.5)));
+    objects.push_back(std::make_unique<sphere const>(vec3{-4, 1, 0}, 1, std::make_unique<lambertian const>(mt, std::make_unique<constant_texture const>(colour{0.4, 0.2, 0.1}))));
+    objects.push_back(std::make_unique<sphere const>(vec3{4, 1, 0}, 1, std::make_unique<metal const>(mt, vec3{0.7, 0.6, 0.5}, 0)));
+
+    std::uniform_real_distribution<double> dist{0, 1};
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            double const cx = a + 0.9 * dist(mt);
+            double const cz = b + 0.9 * dist(mt);
+            vec3 const centre{cx, 0.2, cz};
+            if ((centre - vec3{4, 0.2, 0}).length() <= 0.9) continue;
+            double const choose_mat = dist(mt);
+            if (choose_mat < 0.8) {
+                double const lift = 0.5 * dist(mt);
+                vec3 const offset{0, lift, 0};
+                double const r1 = dist(mt), r2 = dist(mt), g1 = dist(mt), g2 = dist(mt), b1 = dist(mt), b2 = dist(mt);
+                colour const c{r1 * r2, g1 * g2, b1 * b2};
+                objects.push_back(std::make_unique<moving_sphere const>(centre, centre + offset, 0, 1, 0.2,
+                                                                        std::make_unique<lambertian const>(mt, std::make_unique<constant_texture const>(c))));
+            } else if (choose_mat < 0.95) {
+                double const ar = 0.5 * (1 + dist(mt)), ag = 0.5 * (1 + dist(mt)), ab = 0.5 * (1 + dist(mt));
+                double const fuzz = 0.5 * dist(mt);
+                objects.push_back(std::make_unique<sphere const>(centre, 0.2, std::make_unique<metal const>(mt, vec3{ar, ag, ab}, fuzz)));
+            } else {
+                objects.push_back(std::make_unique<sphere const>(centre, 0.2, std::make_unique<dielectric const>(mt, 1.5)));
+            }
+        }
+    }
+    return bvh_node(mt, objects, 0, 1);
+}
+
+}  // namespace rtiow

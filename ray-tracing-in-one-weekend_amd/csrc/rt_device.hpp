@@ -1,0 +1,426 @@
+// rt_device.hpp -- gfx950 device code of the path-tracing hot path: ray/box and
+// ray/sphere tests, BVH traversal, textures, scatter, camera rays and the bounce loop.
+//
+// Everything is IEEE double precision and the translation unit is built with
+// -ffp-contract=off, so each product and sum rounds on its own in the order the
+// reference's expressions evaluate (c++/vec3.cpp:24-74).  Reference citations are
+// file:line under c++/ of hgiddens/ray-tracing-in-one-weekend.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtiow_hip.h"
+
+namespace rtd {
+
+// ---------------------------------------------------------------- scene layout ----
+// One node holds the boxes of BOTH children, so a single fetch decides both descents.
+// A child that is a primitive has no box: the reference tests primitives directly
+// once their parent's box is hit (bvh_node.cpp:57-59).
+struct __attribute__((aligned(16))) DNode {
+    double bx[2][6];   // per child: min x, max x, min y, max y, min z, max z
+    int32_t child[2];  // >= 0 node index, < 0 ~primitive index (device order)
+    uint32_t flags;    // see NF_*
+    uint32_t pad0;
+    double pad1[2];
+};
+static_assert(sizeof(DNode) == 128, "DNode is two 64-byte lines");
+
+enum : uint32_t {
+    NF_MOVING0 = 1u, NF_MOVING1 = 2u,  // child is a moving sphere
+    NF_SAFE0 = 4u, NF_SAFE1 = 8u,      // every primitive under the child stays inside its box: the
+                                       // descent may be skipped once the box starts beyond the best hit
+    NF_SAME = 16u                      // both children are the same object (bvh_node.cpp:31-34)
+};
+
+enum : uint32_t { PK_STATIC = 0, PK_MOVING = 1, PK_MOVING_UNIT = 2 };
+
+struct __attribute__((aligned(16))) DPrim {
+    double c0[3]; double r;    // centre at time0, radius
+    double dc[3]; double t0;   // centre1 - centre0, time0
+    double t1; uint32_t mat; uint32_t kind;
+    int32_t orig; uint32_t pad[3];
+};
+static_assert(sizeof(DPrim) == 96, "DPrim layout");
+
+struct DItem { uint32_t is_bvh; int32_t index; uint32_t moving; uint32_t pad; double box[6]; };
+struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; };
+struct DTex { uint32_t kind; uint32_t even, odd; uint32_t pad; double c[3]; };
+
+struct DScene {
+    const DNode *nodes;
+    const DPrim *prims;
+    const DItem *items;
+    const DMat *mats;
+    const DTex *texs;
+    const double *ranfloat;   // 256
+    const uint8_t *perm;      // 3 x 256: x, y, z
+    uint32_t n_items;
+    uint32_t stack_depth;     // entries per lane
+};
+
+struct DCamera {
+    double origin[3], u[3], v[3], w[3], llc[3], horizontal[3], vertical[3];
+    double lens_radius, t0, t1;
+};
+
+// ------------------------------------------------------------------------ vec3 ----
+struct v3 { double x, y, z; };
+__device__ __forceinline__ v3 mk(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+__device__ __forceinline__ v3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ v3 vadd(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 vmul(v3 a, double d) { return mk(a.x * d, a.y * d, a.z * d); }
+__device__ __forceinline__ v3 vdiv(v3 a, double d) { return mk(a.x / d, a.y / d, a.z / d); }
+__device__ __forceinline__ v3 vneg(v3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double vlen(v3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ v3 vunit(v3 a) { return vdiv(a, vlen(a)); }
+
+struct Ray { v3 o, d; double time; };
+
+// per-segment constants of the slab and sphere tests
+struct RayCtx {
+    v3 o, d;
+    double time;
+    double ix, iy, iz;   // 1/d per axis (aabb.cpp:12,27,42)
+    bool sx, sy, sz;     // 1/d < 0 -> the slab's two planes swap (aabb.cpp:16-18)
+    double a;            // d.d (sphere.cpp:14)
+};
+
+__device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
+    RayCtx c;
+    c.o = r.o; c.d = r.d; c.time = r.time;
+    c.ix = 1.0 / r.d.x; c.iy = 1.0 / r.d.y; c.iz = 1.0 / r.d.z;
+    c.sx = c.ix < 0; c.sy = c.iy < 0; c.sz = c.iz < 0;
+    c.a = vdot(r.d, r.d);
+    return c;
+}
+
+// ------------------------------------------------------------------- random ----
+// Per-path stream: Philox4x32-10 keyed by the render seed over the counter
+// (pixel, sample) gives the start state of a xoshiro128++ generator; a double takes
+// the top 53 bits of two successive 32-bit outputs.
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+struct StreamRng {
+    uint32_t s0, s1, s2, s3;
+    __device__ __forceinline__ void init(uint64_t seed, uint32_t pixel, uint32_t sample) {
+        uint32_t c[4] = {pixel, sample, 0x52544957u, 0u};
+        philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+        s0 = c[0]; s1 = c[1]; s2 = c[2]; s3 = c[3];
+        if ((s0 | s1 | s2 | s3) == 0) s0 = 1u;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint32_t t0 = s0 + s3;
+        uint32_t result = ((t0 << 7) | (t0 >> 25)) + s0;
+        uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+        s2 ^= t;
+        s3 = (s3 << 11) | (s3 >> 21);
+        return result;
+    }
+    __device__ __forceinline__ double canonical() {
+        uint64_t hi = next();
+        uint64_t lo = next();
+        return (double)(((hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+    }
+    __device__ __forceinline__ bool exhausted() const { return false; }
+};
+
+// uniforms handed in by the caller, consumed in order
+struct TapeRng {
+    const double *tape;
+    int len, pos;
+    bool over;
+    __device__ __forceinline__ double canonical() {
+        double u = 0.0;
+        if (pos < len) u = tape[pos]; else over = true;
+        ++pos;
+        return u;
+    }
+    __device__ __forceinline__ bool exhausted() const { return over; }
+};
+
+// std::uniform_real_distribution<double>{a, b}
+template <class R> __device__ __forceinline__ double uniform(R &g, double a, double b) {
+    return (g.canonical() * (b - a)) + a;
+}
+
+// ------------------------------------------------------------------- box test ----
+// aabb::hit (aabb.cpp:8-57).  b = min x, max x, min y, max y, min z, max z.  The bounds
+// only ever tighten and a NaN slab value (0 * inf) leaves them unchanged, so testing
+// once after the third axis decides exactly as the reference's three early exits do.
+__device__ __forceinline__ bool box_test(const double *b, const RayCtx &r, double tmin, double tmax, double &entry) {
+    double t0 = (b[0] - r.o.x) * r.ix, t1 = (b[1] - r.o.x) * r.ix;
+    tmin = __builtin_fmax(r.sx ? t1 : t0, tmin);
+    tmax = __builtin_fmin(r.sx ? t0 : t1, tmax);
+    t0 = (b[2] - r.o.y) * r.iy; t1 = (b[3] - r.o.y) * r.iy;
+    tmin = __builtin_fmax(r.sy ? t1 : t0, tmin);
+    tmax = __builtin_fmin(r.sy ? t0 : t1, tmax);
+    t0 = (b[4] - r.o.z) * r.iz; t1 = (b[5] - r.o.z) * r.iz;
+    tmin = __builtin_fmax(r.sz ? t1 : t0, tmin);
+    tmax = __builtin_fmin(r.sz ? t0 : t1, tmax);
+    entry = tmin;
+    return !(tmax <= tmin);
+}
+
+// ---------------------------------------------------------------- sphere test ----
+// moving_sphere.cpp:3-5
+__device__ __forceinline__ v3 prim_centre(const DPrim *p, uint32_t moving, double time) {
+    v3 c0 = ld3(p->c0);
+    if (!moving) return c0;
+    double s = (p->kind == PK_MOVING_UNIT) ? time : (time - p->t0) / (p->t1 - p->t0);
+    return vadd(c0, vmul(ld3(p->dc), s));
+}
+
+// sphere.cpp:9-45, moving_sphere.cpp:13-49: the root the reference accepts in
+// (tmin, tmax), nearer root first
+__device__ __forceinline__ bool sphere_root(v3 c, double radius, const RayCtx &r, double tmin, double tmax, double &t_out) {
+    v3 oc = vsub(r.o, c);
+    double b = vdot(oc, r.d);
+    double cc = vdot(oc, oc) - radius * radius;
+    double disc = b * b - r.a * cc;
+    bool hit = false;
+    if (disc > 0) {
+        double root = sqrt(disc);
+        double t1 = (-b - root) / r.a;
+        double t2 = (-b + root) / r.a;
+        bool ok1 = t1 < tmax && t1 > tmin;
+        bool ok2 = t2 < tmax && t2 > tmin;
+        t_out = ok1 ? t1 : t2;
+        hit = ok1 || ok2;
+    }
+    return hit;
+}
+
+// ------------------------------------------------------------------ traversal ----
+// bvh_node::hit (bvh_node.cpp:52-69) for the whole tree under `root`, whose own box has
+// already been tested.  The reference visits both children of every node whose box is
+// hit, with the interval it was given, and on equal t keeps the right-hand result; that
+// is "the smallest t, and among equal t the last leaf in left-to-right order".  Leaves
+// are numbered in that order, so any visiting order gives the same answer.  A subtree
+// whose primitives cannot leave their boxes (static spheres) can only produce hits at
+// or after its box's entry point, so it is skipped when that lies beyond the best hit;
+// subtrees holding moving spheres are always visited, because the reference's boxes do
+// not bound them (moving_sphere.cpp:58).
+__device__ __forceinline__ void bvh_closest(const DScene &sc, int root, const RayCtx &r, double tmin, double tmax,
+                                            int *stack, int stride, double &best_t, int &best_prim) {
+    int sp = 0;
+    int cur = root;
+    for (;;) {
+        const DNode *nd = sc.nodes + cur;
+        const uint32_t flags = nd->flags;
+        const int c0 = nd->child[0], c1 = nd->child[1];
+        int go0 = -1, go1 = -1;
+        double e0 = 0, e1 = 0;
+        if (c0 >= 0) {
+            double bx[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bx[k] = nd->bx[0][k];
+            if (box_test(bx, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || best_prim < 0 || e0 <= best_t)) go0 = c0;
+        } else {
+            const DPrim *p = sc.prims + ~c0;
+            double t;
+            if (sphere_root(prim_centre(p, flags & NF_MOVING0, r.time), p->r, r, tmin, tmax, t)) {
+                if (best_prim < 0 || t < best_t || (t == best_t && ~c0 > best_prim)) { best_t = t; best_prim = ~c0; }
+            }
+        }
+        if (c1 >= 0) {
+            double bx[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bx[k] = nd->bx[1][k];
+            if (box_test(bx, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || best_prim < 0 || e1 <= best_t)) go1 = c1;
+        } else if (!(flags & NF_SAME)) {
+            const DPrim *p = sc.prims + ~c1;
+            double t;
+            if (sphere_root(prim_centre(p, flags & NF_MOVING1, r.time), p->r, r, tmin, tmax, t)) {
+                if (best_prim < 0 || t < best_t || (t == best_t && ~c1 > best_prim)) { best_t = t; best_prim = ~c1; }
+            }
+        }
+        if (go0 >= 0 && go1 >= 0) {
+            const bool near0 = e0 <= e1;
+            stack[sp * stride] = near0 ? go1 : go0;
+            ++sp;
+            cur = near0 ? go0 : go1;
+        } else if (go0 >= 0) {
+            cur = go0;
+        } else if (go1 >= 0) {
+            cur = go1;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * stride];
+        }
+    }
+}
+
+// object_list::hit (object_list.cpp:12-26) over the world's items: each item sees the
+// interval narrowed to the closest hit so far and replaces it only with a strictly
+// nearer one.
+__device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r, double tmin, double tmax,
+                                              int *stack, int stride, double &t_out, int &prim_out) {
+    double closest = tmax;
+    int found = -1;
+    for (uint32_t i = 0; i < sc.n_items; ++i) {
+        const DItem *it = sc.items + i;
+        if (it->is_bvh) {
+            double entry;
+            double bx[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bx[k] = it->box[k];
+            if (!box_test(bx, r, tmin, closest, entry)) continue;
+            double bt = 0;
+            int bp = -1;
+            bvh_closest(sc, it->index, r, tmin, closest, stack, stride, bt, bp);
+            if (bp >= 0) { closest = bt; found = bp; }
+        } else {
+            const DPrim *p = sc.prims + it->index;
+            double t;
+            if (sphere_root(prim_centre(p, it->moving, r.time), p->r, r, tmin, closest, t)) { closest = t; found = it->index; }
+        }
+    }
+    t_out = closest;
+    prim_out = found;
+    return found >= 0;
+}
+
+// hit_record of the winning primitive (sphere.cpp:23-29): p = o + t d, n = (p - c) / r
+__device__ __forceinline__ void hit_point(const DScene &sc, int prim, const RayCtx &r, double t, v3 &p, v3 &n) {
+    const DPrim *pr = sc.prims + prim;
+    v3 c = prim_centre(pr, pr->kind != PK_STATIC, r.time);
+    p = vadd(r.o, vmul(r.d, t));
+    n = vdiv(vsub(p, c), pr->r);
+}
+
+// -------------------------------------------------------------------- textures ----
+// perlin.cpp:33-47,55-73
+__device__ __forceinline__ double perlin_noise(const DScene &sc, v3 p) {
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    double accum = 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double lattice = sc.ranfloat[sc.perm[(i + a) & 255] ^ sc.perm[256 + ((j + b) & 255)] ^
+                                             sc.perm[512 + ((k + c) & 255)]];
+                accum += (a * u + (1 - a) * (1 - u)) * (b * v + (1 - b) * (1 - v)) * (c * w + (1 - c) * (1 - w)) * lattice;
+            }
+    return accum;
+}
+
+// texture.hpp:19, texture.cpp:10-18.  Chequer children index earlier table entries, so
+// the walk ends.
+__device__ __forceinline__ v3 texture_value(const DScene &sc, uint32_t tex, v3 p) {
+    const DTex *t = sc.texs + tex;
+    if (t->kind == RT_TEX_CHEQUER) {
+        double sines = sin(10 * p.x) * sin(10 * p.y) * sin(10 * p.z);
+        do {
+            t = sc.texs + (sines < 0 ? t->odd : t->even);
+        } while (t->kind == RT_TEX_CHEQUER);
+    }
+    if (t->kind == RT_TEX_PERLIN) {
+        double grey = perlin_noise(sc, p);
+        return mk(grey, grey, grey);
+    }
+    return ld3(t->c);
+}
+
+// ------------------------------------------------------------------- materials ----
+// material.cpp:35-40
+template <class R> __device__ __forceinline__ v3 random_in_unit_sphere(R &g) {
+    v3 c;
+    do {
+        c.x = uniform(g, -1.0, 1.0);
+        c.y = uniform(g, -1.0, 1.0);
+        c.z = uniform(g, -1.0, 1.0);
+    } while (!(c.x * c.x + c.y * c.y + c.z * c.z < 1) && !g.exhausted());
+    return c;
+}
+
+// material.cpp:10-12
+__device__ __forceinline__ v3 reflect(v3 v, v3 n) { return vsub(v, vmul(n, 2 * vdot(v, n))); }
+
+// material.cpp:47-98.  Returns whether the ray scatters; the draws happen either way.
+template <class R>
+__device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ray &r, v3 p, v3 n, R &g, v3 &att, Ray &out) {
+    const DMat *m = sc.mats + mat;
+    out.o = p;
+    out.time = r.time;
+    if (m->kind == RT_MAT_LAMBERTIAN) {
+        v3 target = vadd(vadd(p, n), random_in_unit_sphere(g));
+        att = texture_value(sc, m->tex, p);
+        out.d = vsub(target, p);
+        return true;
+    }
+    if (m->kind == RT_MAT_METAL) {
+        v3 reflected = reflect(vunit(r.d), n);
+        out.d = vadd(reflected, vmul(random_in_unit_sphere(g), m->fuzz));
+        att = ld3(m->albedo);
+        return vdot(out.d, n) > 0;
+    }
+    // dielectric (material.cpp:77-98, refract :14-24, schlick :26-30)
+    const double ri = m->ri;
+    const double dn = vdot(r.d, n);
+    const bool inside = dn > 0;
+    const v3 outward = inside ? vneg(n) : n;
+    const v3 reflected = reflect(r.d, n);
+    const double ni_over_nt = inside ? ri : 1 / ri;
+    const double len = vlen(r.d);
+    const double cosine = inside ? ri * dn / len : -dn / len;
+    const v3 uv = vdiv(r.d, len);
+    const double dt = vdot(uv, outward);
+    const double disc = 1 - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    double reflect_prob = 1.0;
+    v3 refracted = reflected;
+    if (disc > 0) {
+        refracted = vsub(vmul(vsub(uv, vmul(outward, dt)), ni_over_nt), vmul(outward, sqrt(disc)));
+        double r0 = (1 - ri) / (1 + ri);
+        double r1 = r0 * r0;
+        reflect_prob = r1 + (1 - r1) * pow(1 - cosine, 5.0);
+    }
+    att = mk(1, 1, 1);
+    out.d = uniform(g, 0.0, 1.0) < reflect_prob ? reflected : refracted;
+    return true;
+}
+
+// ---------------------------------------------------------------------- camera ----
+// camera.cpp:16-21,38-48
+template <class R> __device__ __forceinline__ Ray camera_ray(const DCamera &c, double s, double t, R &g) {
+    double px, py;
+    do {
+        px = uniform(g, -1.0, 1.0);
+        py = uniform(g, -1.0, 1.0);
+    } while (!(px * px + py * py + 0.0 * 0.0 < 1) && !g.exhausted());
+    v3 rd = vmul(mk(px, py, 0), c.lens_radius);
+    v3 offset = vadd(vmul(ld3(c.u), rd.x), vmul(ld3(c.v), rd.y));
+    double time = c.t0 + uniform(g, -1.0, 1.0) * (c.t1 - c.t0);
+    Ray r;
+    r.o = vadd(ld3(c.origin), offset);
+    r.d = vsub(vsub(vadd(vadd(ld3(c.llc), vmul(ld3(c.horizontal), s)), vmul(ld3(c.vertical), t)), ld3(c.origin)), offset);
+    r.time = time;
+    return r;
+}
+
+// main.cpp:45-48
+__device__ __forceinline__ v3 sky(v3 d) {
+    v3 unit = vunit(d);
+    double t = 0.5 * (unit.y + 1.0);
+    return mk((1.0 - t) * 1.0 + t * 0.5, (1.0 - t) * 1.0 + t * 0.7, (1.0 - t) * 1.0 + t * 1.0);
+}
+
+}  // namespace rtd

@@ -1,0 +1,640 @@
+// rtiow_hip.hip -- kernels and C ABI (include/rtiow_hip.h) of the MI355X path tracer.
+//
+// Host side: validates a scene description, lays it out for the kernels (nodes with
+// both child boxes, primitives in left-to-right leaf order) and launches.  There is no
+// CPU implementation of any entry point: without a HIP device every call fails.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rt_device.hpp"
+#include "rtiow_hip.h"
+
+using namespace rtd;
+
+// ------------------------------------------------------------------- kernels ----
+namespace {
+
+constexpr int kBlock = 256;  // 4 waves; the render kernel maps them to a 16x16 pixel tile
+
+__device__ __forceinline__ Ray load_ray(const rt_ray *r) {
+    Ray o;
+    o.o = mk(r->origin[0], r->origin[1], r->origin[2]);
+    o.d = mk(r->direction[0], r->direction[1], r->direction[2]);
+    o.time = r->time;
+    return o;
+}
+
+__device__ __forceinline__ void store_ray(rt_ray *r, const Ray &o) {
+    r->origin[0] = o.o.x; r->origin[1] = o.o.y; r->origin[2] = o.o.z;
+    r->direction[0] = o.d.x; r->direction[1] = o.d.y; r->direction[2] = o.d.z;
+    r->time = o.time;
+}
+
+// object::hit for a batch of rays, one ray per lane
+__global__ __launch_bounds__(kBlock) void k_trace_batch(DScene sc, const rt_ray *rays, size_t n, double tmin,
+                                                       double tmax, rt_hit *out) {
+    extern __shared__ int lds_stack[];
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Ray r = load_ray(rays + i);
+    RayCtx ctx = make_ctx(r);
+    double t;
+    int prim;
+    rt_hit h;
+    memset(&h, 0, sizeof h);
+    h.prim = -1;
+    if (world_closest(sc, ctx, tmin, tmax, lds_stack + threadIdx.x, kBlock, t, prim)) {
+        v3 p, nn;
+        hit_point(sc, prim, ctx, t, p, nn);
+        h.hit = 1;
+        h.prim = sc.prims[prim].orig;
+        h.t = t;
+        h.p[0] = p.x; h.p[1] = p.y; h.p[2] = p.z;
+        h.normal[0] = nn.x; h.normal[1] = nn.y; h.normal[2] = nn.z;
+    }
+    out[i] = h;
+}
+
+// aabb::hit for a batch
+__global__ __launch_bounds__(kBlock) void k_aabb_batch(const double *boxes, const rt_ray *rays, const double *tmin,
+                                                      const double *tmax, size_t n, uint8_t *out) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    RayCtx ctx = make_ctx(load_ray(rays + i));
+    const double *b = boxes + i * 6;
+    double bx[6] = {b[0], b[3], b[1], b[4], b[2], b[5]};
+    double entry;
+    out[i] = box_test(bx, ctx, tmin[i], tmax[i], entry) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_texture_batch(DScene sc, uint32_t tex, const double *p, size_t n, double *rgb) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    v3 c = texture_value(sc, tex, mk(p[i * 3], p[i * 3 + 1], p[i * 3 + 2]));
+    rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_batch(DScene sc, const uint32_t *mat, const rt_ray *rays,
+                                                         const rt_hit *hits, const double *tape, uint32_t k, size_t n,
+                                                         uint8_t *scattered, double *att, rt_ray *out, int32_t *used) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    TapeRng g = {tape + i * (size_t)k, (int)k, 0, false};
+    Ray r = load_ray(rays + i);
+    const rt_hit *h = hits + i;
+    v3 a;
+    Ray o;
+    bool s = scatter(sc, mat[i], r, mk(h->p[0], h->p[1], h->p[2]), mk(h->normal[0], h->normal[1], h->normal[2]), g, a, o);
+    scattered[i] = s ? 1 : 0;
+    att[i * 3] = a.x; att[i * 3 + 1] = a.y; att[i * 3 + 2] = a.z;
+    store_ray(out + i, o);
+    used[i] = g.over ? -1 : g.pos;
+}
+
+__global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const double *st, const double *tape, uint32_t k,
+                                                        size_t n, rt_ray *out, int32_t *used) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    TapeRng g = {tape + i * (size_t)k, (int)k, 0, false};
+    Ray r = camera_ray(cam, st[i * 2], st[i * 2 + 1], g);
+    store_ray(out + i, r);
+    used[i] = g.over ? -1 : g.pos;
+}
+
+// The pixel/sample loop (main.cpp:126-141) with ray_colour (main.cpp:30-50) unrolled
+// into one loop over ray segments.  A lane owns one pixel and walks its samples in
+// order; as soon as a path ends the lane starts its next sample, so the lanes of a wave
+// stay busy at different bounce depths instead of waiting for the longest path.
+// Block = 16x16 pixels, wave = 8x8 pixels.
+template <class AccT>
+__global__ __launch_bounds__(kBlock) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
+                                                  uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
+                                                  AccT *accum, unsigned long long *ray_count) {
+    extern __shared__ int lds_stack[];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = x < nx && y < ny;
+    const uint32_t pix = y * nx + x;
+    const uint32_t j = ny - 1 - y;  // the reference's row index runs bottom-up (main.cpp:126)
+    int *stack = lds_stack + tid;
+
+    uint32_t s = inside ? s_begin : s_end;
+    bool alive = false;
+    double sr = 0, sg = 0, sb = 0;
+    Ray r = {mk(0, 0, 0), mk(0, 0, 1), 0};
+    v3 thr = mk(1, 1, 1);
+    uint32_t depth = 0;
+    unsigned long long nrays = 0;
+    StreamRng g = {1, 0, 0, 0};
+
+    for (;;) {
+        if (!alive && s < s_end) {
+            g.init(seed, pix, s);
+            const double ii = (double)x + uniform(g, 0.0, 1.0);
+            const double jj = (double)j + uniform(g, 0.0, 1.0);
+            const double u = ii / (double)nx, v = jj / (double)ny;
+            r = camera_ray(cam, u, v, g);
+            thr = mk(1, 1, 1);
+            depth = 0;
+            alive = true;
+            ++s;
+        }
+        if (!__any(alive)) break;
+        if (alive) {
+            const RayCtx ctx = make_ctx(r);
+            double t;
+            int prim;
+            ++nrays;
+            if (world_closest(sc, ctx, t_min, DBL_MAX, stack, kBlock, t, prim)) {
+                v3 p, nn, att;
+                Ray next;
+                hit_point(sc, prim, ctx, t, p, nn);
+                // scatter first, depth test second (main.cpp:33-34)
+                const bool ok = scatter(sc, sc.prims[prim].mat, r, p, nn, g, att, next);
+                if (depth < max_depth && ok) {
+                    thr = mk(thr.x * att.x, thr.y * att.y, thr.z * att.z);
+                    r = next;
+                    ++depth;
+                } else {
+                    alive = false;  // absorbed or too deep: black (main.cpp:42)
+                }
+            } else {
+                const v3 c = sky(r.d);
+                sr += c.x * thr.x; sg += c.y * thr.y; sb += c.z * thr.z;
+                alive = false;
+            }
+        }
+    }
+    if (inside) {
+        AccT *a = accum + (size_t)pix * 3;
+        a[0] += (AccT)sr; a[1] += (AccT)sg; a[2] += (AccT)sb;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
+    if (lane == 0 && ray_count) atomicAdd(ray_count, nrays);
+}
+
+// supersampler::value, gamma2, convert (supersampler.cpp:12-19, colour.cpp:19-21, main.cpp:26-28)
+__global__ __launch_bounds__(kBlock) void k_resolve(const float *accum, size_t nvals, uint32_t spp, uint8_t *rgb8) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nvals) return;
+    double mean = spp ? (double)accum[i] / (double)spp : 0.0;
+    int q = (int)(255.99 * sqrt(mean));
+    rgb8[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side ----
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(RT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T> struct dev_buf {
+    T *p = nullptr;
+    ~dev_buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
+    hipError_t upload(const T *h, size_t n) {
+        hipError_t e = alloc(n);
+        if (e != hipSuccess || n == 0) return e;
+        return hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    DScene d{};
+    dev_buf<DNode> nodes;
+    dev_buf<DPrim> prims;
+    dev_buf<DItem> items;
+    dev_buf<DMat> mats;
+    dev_buf<DTex> texs;
+    dev_buf<double> ranfloat;
+    dev_buf<uint8_t> perm;
+    dev_buf<unsigned long long> counter;
+    std::vector<uint32_t> material_of_prim;  // by description index
+    uint32_t n_prims_desc = 0, n_textures = 0;
+    size_t lds_bytes = 0;
+};
+
+namespace {
+
+struct flattener {
+    const rt_scene_desc *desc;
+    std::vector<DNode> nodes;
+    std::vector<DPrim> prims;
+    uint32_t max_depth = 0;
+    const char *error = nullptr;
+
+    int emit_prim(int32_t id, bool &moving, bool &safe) {
+        const rt_prim_desc &p = desc->prims[id];
+        DPrim d;
+        memset(&d, 0, sizeof d);
+        for (int k = 0; k < 3; ++k) { d.c0[k] = p.centre0[k]; d.dc[k] = p.centre1[k] - p.centre0[k]; }
+        d.r = p.radius; d.t0 = p.time0; d.t1 = p.time1;
+        d.mat = p.material;
+        d.orig = id;
+        moving = p.kind == RT_PRIM_MOVING_SPHERE;
+        if (!moving) {
+            d.kind = PK_STATIC;
+            for (int k = 0; k < 3; ++k) d.dc[k] = 0;
+        } else {
+            d.kind = (p.time0 == 0.0 && p.time1 == 1.0) ? PK_MOVING_UNIT : PK_MOVING;
+        }
+        // a sphere that never moves stays inside the box the reference gives it
+        safe = !moving;
+        prims.push_back(d);
+        return (int)prims.size() - 1;
+    }
+
+    // returns the device index of the node built for description node `id`
+    int build(int32_t id, uint32_t depth, bool &safe) {
+        if (error) return 0;
+        if (depth > 64) { error = "bvh deeper than 64 levels (or cyclic)"; return 0; }
+        if (nodes.size() > (1u << 26)) { error = "bvh larger than 2^26 nodes"; return 0; }
+        if (depth + 1 > max_depth) max_depth = depth + 1;
+        const rt_node_desc nd = desc->nodes[id];
+        const int me = (int)nodes.size();
+        nodes.emplace_back();
+        DNode out;
+        memset(&out, 0, sizeof out);
+        bool safe_c[2] = {true, true};
+        const int32_t ref[2] = {nd.left, nd.right};
+        for (int c = 0; c < 2; ++c) {
+            if (c == 1 && ref[1] == ref[0] && ref[0] < 0) {
+                out.child[1] = out.child[0];
+                out.flags |= NF_SAME;
+                if (out.flags & NF_MOVING0) out.flags |= NF_MOVING1;
+                safe_c[1] = safe_c[0];
+                continue;
+            }
+            if (ref[c] >= 0) {
+                if ((uint32_t)ref[c] >= desc->n_nodes) { error = "node child out of range"; return 0; }
+                const rt_node_desc &ch = desc->nodes[ref[c]];
+                for (int a = 0; a < 3; ++a) { out.bx[c][2 * a] = ch.box_min[a]; out.bx[c][2 * a + 1] = ch.box_max[a]; }
+                out.child[c] = build(ref[c], depth + 1, safe_c[c]);
+                if (error) return 0;
+            } else {
+                if ((uint32_t)~ref[c] >= desc->n_prims) { error = "node primitive out of range"; return 0; }
+                bool moving;
+                out.child[c] = ~emit_prim(~ref[c], moving, safe_c[c]);
+                if (moving) out.flags |= (c == 0 ? NF_MOVING0 : NF_MOVING1);
+            }
+        }
+        if (safe_c[0]) out.flags |= NF_SAFE0;
+        if (safe_c[1]) out.flags |= NF_SAFE1;
+        safe = safe_c[0] && safe_c[1];
+        nodes[me] = out;
+        return me;
+    }
+};
+
+int check_desc(const rt_scene_desc *d) {
+    if (!d) return fail(RT_E_INVALID, "null scene description");
+    if ((d->n_textures && !d->textures) || (d->n_materials && !d->materials) || (d->n_prims && !d->prims) ||
+        (d->n_nodes && !d->nodes) || (d->n_items && !d->items))
+        return fail(RT_E_INVALID, "scene description has a null table with a non-zero count");
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const rt_texture_desc &t = d->textures[i];
+        if (t.kind > RT_TEX_PERLIN) return fail(RT_E_INVALID, "texture %u: unknown kind %u", i, t.kind);
+        if (t.kind == RT_TEX_CHEQUER && (t.even >= i || t.odd >= i))
+            return fail(RT_E_INVALID, "texture %u: chequer children must index earlier textures", i);
+        if (t.kind == RT_TEX_PERLIN && (!d->perlin_ranfloat || !d->perlin_perm_x || !d->perlin_perm_y || !d->perlin_perm_z))
+            return fail(RT_E_INVALID, "texture %u: perlin texture without perlin tables", i);
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rt_material_desc &m = d->materials[i];
+        if (m.kind > RT_MAT_DIELECTRIC) return fail(RT_E_INVALID, "material %u: unknown kind %u", i, m.kind);
+        if (m.kind == RT_MAT_LAMBERTIAN && m.texture >= d->n_textures)
+            return fail(RT_E_INVALID, "material %u: texture %u out of range", i, m.texture);
+    }
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const rt_prim_desc &p = d->prims[i];
+        if (p.kind > RT_PRIM_MOVING_SPHERE) return fail(RT_E_INVALID, "primitive %u: unknown kind %u", i, p.kind);
+        if (p.material >= d->n_materials) return fail(RT_E_INVALID, "primitive %u: material %u out of range", i, p.material);
+    }
+    for (uint32_t i = 0; i < d->n_items; ++i) {
+        const rt_item_desc &it = d->items[i];
+        if (it.index < 0 || (uint32_t)it.index >= (it.is_bvh ? d->n_nodes : d->n_prims))
+            return fail(RT_E_INVALID, "item %u: index %d out of range", i, it.index);
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+    if (!out) return fail(RT_E_INVALID, "null output handle");
+    *out = nullptr;
+    if (int rc = check_desc(desc)) return rc;
+    int ndev = rt_device_count();
+    if (ndev <= 0) return fail(RT_E_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(RT_E_INVALID, "device %d out of range (have %d)", device, ndev);
+
+    flattener fl;
+    fl.desc = desc;
+    std::vector<DItem> items;
+    for (uint32_t i = 0; i < desc->n_items; ++i) {
+        const rt_item_desc &it = desc->items[i];
+        DItem di;
+        memset(&di, 0, sizeof di);
+        di.is_bvh = it.is_bvh ? 1u : 0u;
+        if (it.is_bvh) {
+            const rt_node_desc &root = desc->nodes[it.index];
+            for (int a = 0; a < 3; ++a) { di.box[2 * a] = root.box_min[a]; di.box[2 * a + 1] = root.box_max[a]; }
+            bool safe;
+            di.index = fl.build(it.index, 0, safe);
+            if (fl.error) return fail(RT_E_UNSUPPORTED, "%s", fl.error);
+        } else {
+            bool moving, safe;
+            di.index = fl.emit_prim(it.index, moving, safe);
+            di.moving = moving ? 1u : 0u;
+        }
+        items.push_back(di);
+    }
+
+    rt_scene *s = new (std::nothrow) rt_scene;
+    if (!s) return fail(RT_E_INVALID, "out of host memory");
+    s->device = device;
+    s->n_prims_desc = desc->n_prims;
+    s->n_textures = desc->n_textures;
+    s->material_of_prim.resize(desc->n_prims);
+    for (uint32_t i = 0; i < desc->n_prims; ++i) s->material_of_prim[i] = desc->prims[i].material;
+
+    std::vector<DMat> mats(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const rt_material_desc &m = desc->materials[i];
+        DMat d;
+        memset(&d, 0, sizeof d);
+        d.kind = m.kind; d.tex = m.texture; d.fuzz = m.fuzziness; d.ri = m.refractive_index;
+        for (int k = 0; k < 3; ++k) d.albedo[k] = m.albedo[k];
+        mats[i] = d;
+    }
+    std::vector<DTex> texs(desc->n_textures);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const rt_texture_desc &t = desc->textures[i];
+        DTex d;
+        memset(&d, 0, sizeof d);
+        d.kind = t.kind; d.even = t.even; d.odd = t.odd;
+        for (int k = 0; k < 3; ++k) d.c[k] = t.colour[k];
+        texs[i] = d;
+    }
+    std::vector<double> ranfloat(256, 0.0);
+    std::vector<uint8_t> perm(768, 0);
+    if (desc->perlin_ranfloat && desc->perlin_perm_x && desc->perlin_perm_y && desc->perlin_perm_z) {
+        memcpy(ranfloat.data(), desc->perlin_ranfloat, 256 * sizeof(double));
+        memcpy(perm.data(), desc->perlin_perm_x, 256);
+        memcpy(perm.data() + 256, desc->perlin_perm_y, 256);
+        memcpy(perm.data() + 512, desc->perlin_perm_z, 256);
+    }
+
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
+    if (e == hipSuccess) e = s->prims.upload(fl.prims.data(), fl.prims.size());
+    if (e == hipSuccess) e = s->items.upload(items.data(), items.size());
+    if (e == hipSuccess) e = s->mats.upload(mats.data(), mats.size());
+    if (e == hipSuccess) e = s->texs.upload(texs.data(), texs.size());
+    if (e == hipSuccess) e = s->ranfloat.upload(ranfloat.data(), ranfloat.size());
+    if (e == hipSuccess) e = s->perm.upload(perm.data(), perm.size());
+    if (e == hipSuccess) e = s->counter.alloc(1);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
+    }
+    s->d.nodes = s->nodes.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
+    s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
+    s->d.n_items = (uint32_t)items.size();
+    s->d.stack_depth = fl.max_depth + 2;
+    s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int rt_trace_batch(rt_scene *scene, const rt_ray *rays, size_t n, double t_min, double t_max, rt_hit *out) {
+    if (!scene || (n && (!rays || !out))) return fail(RT_E_INVALID, "rt_trace_batch: null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(scene->device));
+    dev_buf<rt_ray> d_rays;
+    dev_buf<rt_hit> d_out;
+    HIP_TRY(d_rays.upload(rays, n));
+    HIP_TRY(d_out.alloc(n));
+    hipLaunchKernelGGL(k_trace_batch, dim3(grid_for(n)), dim3(kBlock), scene->lds_bytes, 0, scene->d, d_rays.p, n, t_min,
+                       t_max, d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_aabb_hit_batch(int device, const double *boxes, const rt_ray *rays, const double *t_min, const double *t_max,
+                      size_t n, uint8_t *out) {
+    if (n && (!boxes || !rays || !t_min || !t_max || !out)) return fail(RT_E_INVALID, "rt_aabb_hit_batch: null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    dev_buf<double> d_boxes, d_tmin, d_tmax;
+    dev_buf<rt_ray> d_rays;
+    dev_buf<uint8_t> d_out;
+    HIP_TRY(d_boxes.upload(boxes, n * 6));
+    HIP_TRY(d_rays.upload(rays, n));
+    HIP_TRY(d_tmin.upload(t_min, n));
+    HIP_TRY(d_tmax.upload(t_max, n));
+    HIP_TRY(d_out.alloc(n));
+    hipLaunchKernelGGL(k_aabb_batch, dim3(grid_for(n)), dim3(kBlock), 0, 0, d_boxes.p, d_rays.p, d_tmin.p, d_tmax.p, n, d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_texture_batch(rt_scene *scene, uint32_t texture, const double *p, size_t n, double *rgb) {
+    if (!scene || (n && (!p || !rgb))) return fail(RT_E_INVALID, "rt_texture_batch: null argument");
+    if (texture >= scene->n_textures) return fail(RT_E_INVALID, "rt_texture_batch: texture %u out of range", texture);
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(scene->device));
+    dev_buf<double> d_p, d_rgb;
+    HIP_TRY(d_p.upload(p, n * 3));
+    HIP_TRY(d_rgb.alloc(n * 3));
+    hipLaunchKernelGGL(k_texture_batch, dim3(grid_for(n)), dim3(kBlock), 0, 0, scene->d, texture, d_p.p, n, d_rgb.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rgb, d_rgb.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_scatter_batch(rt_scene *scene, const int32_t *prim, const rt_ray *rays, const rt_hit *hits, const double *tape,
+                     uint32_t k, size_t n, uint8_t *scattered, double *attenuation, rt_ray *out, int32_t *used) {
+    if (!scene || (n && (!prim || !rays || !hits || !scattered || !attenuation || !out || !used)) || (n && k && !tape))
+        return fail(RT_E_INVALID, "rt_scatter_batch: null argument");
+    if (n == 0) return RT_OK;
+    std::vector<uint32_t> mat(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (prim[i] < 0 || (uint32_t)prim[i] >= scene->n_prims_desc)
+            return fail(RT_E_INVALID, "rt_scatter_batch: item %zu: primitive %d out of range", i, prim[i]);
+        mat[i] = scene->material_of_prim[prim[i]];
+    }
+    HIP_TRY(hipSetDevice(scene->device));
+    dev_buf<uint32_t> d_mat;
+    dev_buf<rt_ray> d_rays, d_out;
+    dev_buf<rt_hit> d_hits;
+    dev_buf<double> d_tape, d_att;
+    dev_buf<uint8_t> d_sc;
+    dev_buf<int32_t> d_used;
+    HIP_TRY(d_mat.upload(mat.data(), n));
+    HIP_TRY(d_rays.upload(rays, n));
+    HIP_TRY(d_hits.upload(hits, n));
+    HIP_TRY(d_tape.upload(tape, n * (size_t)k));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(d_att.alloc(n * 3));
+    HIP_TRY(d_sc.alloc(n));
+    HIP_TRY(d_used.alloc(n));
+    hipLaunchKernelGGL(k_scatter_batch, dim3(grid_for(n)), dim3(kBlock), 0, 0, scene->d, d_mat.p, d_rays.p, d_hits.p,
+                       d_tape.p, k, n, d_sc.p, d_att.p, d_out.p, d_used.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(scattered, d_sc.p, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(attenuation, d_att.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(used, d_used.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+        if (used[i] < 0) return fail(RT_E_TAPE, "rt_scatter_batch: item %zu needs more than %u uniforms", i, k);
+    return RT_OK;
+}
+
+static DCamera to_dcamera(const rt_camera *c) {
+    DCamera d;
+    for (int k = 0; k < 3; ++k) {
+        d.origin[k] = c->origin[k]; d.u[k] = c->u[k]; d.v[k] = c->v[k]; d.w[k] = c->w[k];
+        d.llc[k] = c->lower_left_corner[k]; d.horizontal[k] = c->horizontal[k]; d.vertical[k] = c->vertical[k];
+    }
+    d.lens_radius = c->lens_radius; d.t0 = c->time0; d.t1 = c->time1;
+    return d;
+}
+
+int rt_camera_batch(int device, const rt_camera *camera, const double *st, const double *tape, uint32_t k, size_t n,
+                    rt_ray *out, int32_t *used) {
+    if (!camera || (n && (!st || !out || !used)) || (n && k && !tape)) return fail(RT_E_INVALID, "rt_camera_batch: null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    dev_buf<double> d_st, d_tape;
+    dev_buf<rt_ray> d_out;
+    dev_buf<int32_t> d_used;
+    HIP_TRY(d_st.upload(st, n * 2));
+    HIP_TRY(d_tape.upload(tape, n * (size_t)k));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(d_used.alloc(n));
+    hipLaunchKernelGGL(k_camera_batch, dim3(grid_for(n)), dim3(kBlock), 0, 0, to_dcamera(camera), d_st.p, d_tape.p, k, n,
+                       d_out.p, d_used.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(used, d_used.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+        if (used[i] < 0) return fail(RT_E_TAPE, "rt_camera_batch: item %zu needs more than %u uniforms", i, k);
+    return RT_OK;
+}
+
+int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, void *stream_v,
+              rt_stats *stats) {
+    if (!scene || !camera || !pr || !accum_dev) return fail(RT_E_INVALID, "rt_render: null argument");
+    if (pr->nx == 0 || pr->ny == 0) return fail(RT_E_INVALID, "rt_render: empty image");
+    if ((uint64_t)pr->nx * pr->ny > 0xFFFFFFFFull / 3) return fail(RT_E_INVALID, "rt_render: image too large");
+    if (pr->sample_end < pr->sample_begin) return fail(RT_E_INVALID, "rt_render: sample_end < sample_begin");
+    if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render: unknown accum_type %u", pr->accum_type);
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        HIP_TRY(hipMemsetAsync(scene->counter.p, 0, sizeof(unsigned long long), stream));
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    dim3 grid((pr->nx + 15) / 16, (pr->ny + 15) / 16), block(kBlock);
+    DCamera cam = to_dcamera(camera);
+    unsigned long long *counter = stats ? scene->counter.p : nullptr;
+    if (pr->accum_type == RT_ACCUM_F32)
+        hipLaunchKernelGGL(k_render<float>, grid, block, scene->lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
+                           pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (float *)accum_dev, counter);
+    else
+        hipLaunchKernelGGL(k_render<double>, grid, block, scene->lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
+                           pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (double *)accum_dev, counter);
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        unsigned long long rays = 0;
+        HIP_TRY(hipMemcpy(&rays, scene->counter.p, sizeof rays, hipMemcpyDeviceToHost));
+        stats->kernel_ms = ms;
+        stats->rays = rays;
+        stats->paths = (uint64_t)pr->nx * pr->ny * (pr->sample_end - pr->sample_begin);
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    return RT_OK;
+}
+
+int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_host, rt_stats *stats) {
+    if (!scene || !camera || !pr || !accum_host) return fail(RT_E_INVALID, "rt_render_host: null argument");
+    if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render_host: unknown accum_type %u", pr->accum_type);
+    HIP_TRY(hipSetDevice(scene->device));
+    size_t bytes = (size_t)pr->nx * pr->ny * 3 * (pr->accum_type == RT_ACCUM_F32 ? sizeof(float) : sizeof(double));
+    dev_buf<uint8_t> d;
+    HIP_TRY(d.alloc(bytes));
+    HIP_TRY(hipMemset(d.p, 0, bytes));
+    if (int rc = rt_render(scene, camera, pr, d.p, nullptr, stats)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum_host, d.p, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_resolve(int device, const float *accum_dev, size_t npix, uint32_t spp, uint8_t *rgb8_dev, void *stream) {
+    if (npix && (!accum_dev || !rgb8_dev)) return fail(RT_E_INVALID, "rt_resolve: null argument");
+    if (npix == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(npix * 3)), dim3(kBlock), 0, (hipStream_t)stream, accum_dev, npix * 3, spp, rgb8_dev);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // extern "C"
