@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one frame's worth of samples: every rank renders
+`--spp` samples of every pixel of the 1920x1080 random-spheres frame (BASELINE.json
+configs[1]) with the per-(pixel, sample) random streams, rank r taking the global sample
+indices [r*spp, (r+1)*spp), and the float accumulation buffers are summed with one RCCL
+all-reduce (weak scaling: per-GPU work is fixed as N grows).  The scene is uploaded once
+and stays resident in HBM; only kernels and the all-reduce are inside the timed region.
+
+Rank 0 prints ONE JSON line.  `value` is whole-job Mpaths/s (1 path = 1 camera sample
+followed through all its bounces).  `roofline` prices the render kernel against HBM peak
+with the algorithmic bytes of reference-semantics traversal (32 B per box test, 16 B per
+static-sphere test, 40 B per moving-sphere test, 12 B of framebuffer per pixel), the
+per-path counts measured by the CPU oracle on the same scene and camera.  `cpu_baseline`
+times the compiled reference classes (oracle/_ref/ref_capture) -- or the C oracle when
+that binary is absent -- on one host core over a bounded sample of the same frame.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
+FP64_PEAK_TFLOPS = 78.6      # MI355X vector FP64
+
+
+def book_camera(aspect):
+    # main.cpp:114-120
+    return [13.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 20.0, aspect, 0.0, 10.0, 0.0, 1.0]
+
+
+def algorithmic_counts(scene_path, cam15):
+    """Per-path work of the reference's traversal, measured by the oracle on a small frame of
+    the same scene and camera (the per-path averages do not depend on resolution)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    s = oracle_lib.Scene(scene_path)
+    nx, ny, ns = 192, 108, 4
+    _, c = s.render(cam15, nx, ny, 0, ns, 1, oracle_lib.ORC_RNG_STREAM)
+    paths = float(c.paths)
+    return {"rays_per_path": c.rays / paths, "box_tests_per_ray": c.box_tests / c.rays,
+            "sphere_tests_per_ray": c.sphere_tests / c.rays, "moving_tests_per_ray": c.moving_tests / c.rays}
+
+
+def cpu_baseline(scene_path, cam15, nx, ny):
+    """The reference renderer on one host core over a bounded sample of the same frame."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_capture")
+    spp = 2
+    if os.path.exists(ref):
+        out = subprocess.run([ref, "render", scene_path, "1", str(nx), str(ny), str(spp), *map(repr, cam15), "-"],
+                             check=True, capture_output=True, text=True).stdout
+        r = json.loads(out)
+        return {"value": r["mpaths_per_s"], "unit": "Mpaths/s", "cores": 1, "kind": "reference",
+                "sample": f"{nx}x{ny} at {spp} spp ({nx * ny * spp / 1e6:.2f} M paths, {r['render_seconds']:.1f} s), "
+                          "reference classes built with the reference's flags (-O3 -D_GLIBCXX_DEBUG -DNDEBUG), single thread as shipped"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    s = oracle_lib.Scene(scene_path)
+    t0 = time.perf_counter()
+    s.render(cam15, nx, ny, 0, 1, 1, oracle_lib.ORC_RNG_MT)
+    dt = time.perf_counter() - t0
+    return {"value": nx * ny / dt / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
+            "sample": f"{nx}x{ny} at 1 spp ({dt:.1f} s), C restatement of the reference (oracle/rt_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="book1", help="recipe name under tests/golden/scenes or a recipe path")
+    ap.add_argument("--nx", type=int, default=1920)
+    ap.add_argument("--ny", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
+    scene_path = args.scene if os.path.exists(args.scene) else os.path.join(SCENES, args.scene + ".recipe")
+    cam15 = book_camera(args.nx / args.ny)
+    w = rt.World(scene_path, device=local_rank)
+    cam = rt.camera(cam15)
+
+    accum = torch.zeros(args.ny, args.nx, 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    params = w.params(args.nx, args.ny, rank * args.spp, (rank + 1) * args.spp, seed=1, accum=rt.RT_ACCUM_F32)
+    kernel_ms = []
+
+    def step(record):
+        accum.zero_()
+        stats = rt.rt_stats() if record else None
+        w.render_device(cam, params, accum.data_ptr(), stream, stats)
+        if world > 1:
+            dist.all_reduce(accum)          # RCCL sum over xGMI
+        if record:
+            kernel_ms.append(stats.kernel_ms)
+            return stats
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    paths_per_step = args.nx * args.ny * args.spp * world
+    value = paths_per_step * args.steps / elapsed / 1e6
+    mean = float(accum.mean().item()) / (args.spp * world)
+
+    if rank == 0:
+        counts = algorithmic_counts(scene_path, cam15)
+        bytes_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 32 + counts["sphere_tests_per_ray"] * 16 +
+                                                    counts["moving_tests_per_ray"] * 40) + 12.0 / args.spp
+        flops_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 27 + (counts["sphere_tests_per_ray"] +
+                                                    counts["moving_tests_per_ray"]) * 30 + 60)
+        k_s = float(np.mean(kernel_ms)) / 1e3
+        launch_paths = args.nx * args.ny * args.spp
+        achieved = launch_paths * bytes_per_path / k_s / 1e9
+        line = {
+            "metric": "Mpaths/s at 1080p random-spheres", "value": value, "unit": "Mpaths/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.scene}: book-1 random spheres ({args.nx}x{args.ny}, {args.spp} spp per GPU per step, "
+                                   "max depth 50, BVH built by the reference algorithm)",
+                       "nx": args.nx, "ny": args.ny, "spp_per_gpu": args.spp, "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
+            "rays_per_path": last.rays / last.paths, "mean_radiance": mean,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_render<float>", "kernel_ms": k_s * 1e3,
+                         "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,
+                         "valu_f64": {"achieved_tflops": launch_paths * flops_per_path / k_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
+                                      "frac": launch_paths * flops_per_path / k_s / 1e12 / FP64_PEAK_TFLOPS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene_path, cam15, args.nx, args.ny)
+        print(json.dumps(line), flush=True)
+    w.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

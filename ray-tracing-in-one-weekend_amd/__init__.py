@@ -122,6 +122,8 @@ def host():
         lib.rth_world_scene.restype = ctypes.c_void_p
         lib.rth_world_desc.argtypes = [ctypes.c_void_p]
         lib.rth_world_desc.restype = ctypes.POINTER(rt_scene_desc)
+        lib.rth_world_recipe_ids.argtypes = [ctypes.c_void_p]
+        lib.rth_world_recipe_ids.restype = ctypes.POINTER(ctypes.c_int32)
         lib.rth_camera.argtypes = [ctypes.c_void_p, ctypes.POINTER(rt_camera)]
         lib.rth_perlin_tables.argtypes = [ctypes.c_void_p] * 4
         _host = lib
@@ -156,11 +158,18 @@ def perlin_tables():
     return ran, px, py, pz
 
 
-def _tables(desc):
+def _recipe_ids(h):
+    n = host().rth_world_desc(h).contents.n_prims
+    return np.ctypeslib.as_array(host().rth_world_recipe_ids(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+
+
+def _tables(desc, ids):
+    """nodes[n,8] = box min(3) max(3) left right with primitive children as ~(recipe number)."""
     nodes = np.zeros((desc.n_nodes, 8), np.float64)
+    ref = lambda c: c if c >= 0 else ~int(ids[~c])
     for i in range(desc.n_nodes):
         n = desc.nodes[i]
-        nodes[i] = [*n.box_min, *n.box_max, n.left, n.right]
+        nodes[i] = [*n.box_min, *n.box_max, ref(n.left), ref(n.right)]
     items = np.array([(desc.items[i].is_bvh, desc.items[i].index) for i in range(desc.n_items)], dtype=np.int64).reshape(-1, 2)
     return nodes, items
 
@@ -172,7 +181,7 @@ def world_tables(recipe_path):
     if host().rth_world_tables(recipe_path.encode(), ctypes.byref(h)):
         raise RtError(host().rth_last_error().decode())
     try:
-        return _tables(host().rth_world_desc(h).contents)
+        return _tables(host().rth_world_desc(h).contents, _recipe_ids(h))
     finally:
         host().rth_world_free(h)
 
@@ -210,6 +219,8 @@ class World:
         if host().rth_world_load(recipe_path.encode(), device, ctypes.byref(self._h)):
             raise RtError(host().rth_last_error().decode())
         self.scene = host().rth_world_scene(self._h)
+        self.recipe_ids = _recipe_ids(self._h)   # table primitive -> recipe primitive
+        self.table_ids = np.argsort(self.recipe_ids).astype(np.int32)
 
     def close(self):
         if self._h:
@@ -223,12 +234,14 @@ class World:
             pass
 
     def tables(self):
-        return _tables(host().rth_world_desc(self._h).contents)
+        return _tables(host().rth_world_desc(self._h).contents, self.recipe_ids)
 
     def trace(self, rays, tmin, tmax):
         rays = np.ascontiguousarray(rays, dtype=np.float64)
         out = np.zeros(len(rays), HIT_DTYPE)
         _check(hip().rt_trace_batch(self.scene, _ptr(rays), len(rays), tmin, tmax, _ptr(out)), "rt_trace_batch")
+        m = out["hit"] != 0
+        out["prim"][m] = self.recipe_ids[out["prim"][m]]   # report recipe numbering
         return out
 
     def texture(self, tex, points):
@@ -238,7 +251,7 @@ class World:
         return out
 
     def scatter(self, prim, rays, hits, tape):
-        prim = np.ascontiguousarray(prim, dtype=np.int32)
+        prim = np.ascontiguousarray(self.table_ids[np.asarray(prim, dtype=np.int64)], dtype=np.int32)   # recipe -> table numbering
         rays = np.ascontiguousarray(rays, dtype=np.float64)
         tape = np.ascontiguousarray(tape, dtype=np.float64)
         n, k = len(prim), tape.shape[1]

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <map>
+#include <vector>
 #include <memory>
 #include <string>
 
@@ -37,6 +39,14 @@ struct rth_world {
     std::unique_ptr<device_scene> scene;
     std::unique_ptr<scene_flattener> flat;   // tables of a world that was not uploaded
     rt_scene_desc desc{};
+    std::vector<int32_t> recipe_id;           // recipe primitive number of each table primitive
+
+    void number_prims(scene_flattener const& tables, std::vector<material const*> const& by_prim) {
+        std::map<material const*, int32_t> id;
+        for (size_t i = 0; i < by_prim.size(); ++i) id[by_prim[i]] = (int32_t)i;
+        recipe_id.clear();
+        for (material const* m : tables.material_of_prim) recipe_id.push_back(id.at(m));
+    }
 };
 
 extern "C" {
@@ -64,9 +74,11 @@ int rth_world_load(const char* recipe_path, int device, rth_world** out) {
     return guarded([&] {
         auto w = std::make_unique<rth_world>();
         recipe const rc = recipe::load(recipe_path);
-        w->world = rc.instantiate(w->mt);
+        std::vector<material const*> by_prim;
+        w->world = rc.instantiate(w->mt, &by_prim);
         w->scene = std::make_unique<device_scene>(*w->world, device);
         w->desc = w->scene->tables().desc();
+        w->number_prims(w->scene->tables(), by_prim);
         *out = w.release();
     });
 }
@@ -75,16 +87,22 @@ void rth_world_free(rth_world* w) { delete w; }
 rt_scene* rth_world_scene(rth_world* w) { return w->scene->get(); }
 const rt_scene_desc* rth_world_desc(rth_world* w) { return &w->desc; }
 
+// The tables number primitives in the order the world was flattened (left-to-right leaf
+// order); this gives, for each of them, its number in the recipe (construction order).
+const int32_t* rth_world_recipe_ids(rth_world* w) { return w->recipe_id.data(); }
+
 // Flattens a recipe's world without touching a GPU: tables only (for host-side checks).
 int rth_world_tables(const char* recipe_path, rth_world** out) {
     *out = nullptr;
     return guarded([&] {
         auto w = std::make_unique<rth_world>();
         recipe const rc = recipe::load(recipe_path);
-        w->world = rc.instantiate(w->mt);
+        std::vector<material const*> by_prim;
+        w->world = rc.instantiate(w->mt, &by_prim);
         w->flat = std::make_unique<scene_flattener>();
         w->world->flatten_items(*w->flat);
         w->desc = w->flat->desc();
+        w->number_prims(*w->flat, by_prim);
         *out = w.release();
     });
 }

@@ -161,25 +161,27 @@ std::unique_ptr<material const> make_material(recipe const& rc, int id, std::mt1
     return std::make_unique<dielectric const>(mt, m.ri);
 }
 
-std::unique_ptr<object const> make_prim(recipe const& rc, int id, std::mt19937& mt) {
+std::unique_ptr<object const> make_prim(recipe const& rc, int id, std::mt19937& mt, std::vector<material const*>* by_prim) {
     recipe::prim const& p = rc.prims[(size_t)id];
-    if (p.kind == RT_PRIM_SPHERE) return std::make_unique<sphere const>(vec3{p.c0[0], p.c0[1], p.c0[2]}, p.r, make_material(rc, p.mat, mt));
-    return std::make_unique<moving_sphere const>(vec3{p.c0[0], p.c0[1], p.c0[2]}, vec3{p.c1[0], p.c1[1], p.c1[2]}, p.t0, p.t1, p.r,
-                                                 make_material(rc, p.mat, mt));
+    std::unique_ptr<material const> m = make_material(rc, p.mat, mt);
+    if (by_prim) (*by_prim)[(size_t)id] = m.get();
+    if (p.kind == RT_PRIM_SPHERE) return std::make_unique<sphere const>(vec3{p.c0[0], p.c0[1], p.c0[2]}, p.r, std::move(m));
+    return std::make_unique<moving_sphere const>(vec3{p.c0[0], p.c0[1], p.c0[2]}, vec3{p.c1[0], p.c1[1], p.c1[2]}, p.t0, p.t1, p.r, std::move(m));
 }
 
 }  // namespace
 
-std::unique_ptr<object const> recipe::instantiate(std::mt19937& mt) const {
+std::unique_ptr<object const> recipe::instantiate(std::mt19937& mt, std::vector<material const*>* by_prim) const {
+    if (by_prim) by_prim->assign(prims.size(), nullptr);
     std::vector<std::unique_ptr<object const>> world;
     for (item const& it : items) {
         if (!it.is_bvh) {
-            world.push_back(make_prim(*this, it.first, mt));
+            world.push_back(make_prim(*this, it.first, mt, by_prim));
             continue;
         }
         std::vector<std::unique_ptr<object const>> objs;
         objs.reserve((size_t)it.count);
-        for (int k = 0; k < it.count; ++k) objs.push_back(make_prim(*this, it.first + k, mt));
+        for (int k = 0; k < it.count; ++k) objs.push_back(make_prim(*this, it.first + k, mt, by_prim));
         std::mt19937 bm(it.seed);
         world.push_back(std::make_unique<bvh_node const>(bm, objs, it.t0, it.t1));
     }

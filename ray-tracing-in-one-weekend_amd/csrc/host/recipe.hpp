@@ -40,8 +40,9 @@ struct recipe {
 
     // Builds the world through the public constructors.  Materials are bound to `mt`
     // (every primitive gets its own material object, as the reference's ownership
-    // requires); each bvh group uses its own generator.
-    std::unique_ptr<object const> instantiate(std::mt19937& mt) const;
+    // requires); each bvh group uses its own generator.  When `material_by_prim` is given
+    // it receives, per recipe primitive, the material object created for it.
+    std::unique_ptr<object const> instantiate(std::mt19937& mt, std::vector<material const*>* material_by_prim = nullptr) const;
 
     int add_constant(double r, double g, double b);
     int add_lambertian(int tex);

@@ -1,0 +1,256 @@
+"""GPU parity: every entry point of include/rtiow_hip.h against the golden vectors
+captured from the compiled reference and against the oracle on the same inputs.
+
+Bars (BASELINE.json north_star): hit/miss and primitive id bit-exact; t, p, normal within
+1e-5 relative -- these tests hold them to bit-exact, which the double-precision,
+unfused arithmetic achieves.  Frames: the GPU renders the very paths the oracle renders
+when both use the per-(pixel, sample) streams, so sums agree to rounding (1e-11 relative;
+the product of attenuations is taken in the opposite order); against the reference's own
+mt19937 frames the comparison is statistical, with the Monte-Carlo noise floor measured
+from two reference seeds.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import TRACE_SCENES, golden, recipe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def worlds(rt):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = rt.World(recipe(name))
+        return cache[name]
+    yield get
+    for w in cache.values():
+        w.close()
+
+
+def test_device_present(rt):
+    assert rt.hip().rt_device_count() >= 1
+
+
+def test_aabb_hit(rt, orc):
+    g = golden("aabb")
+    got = rt.aabb_hit_batch(g["cases"])
+    assert np.array_equal(got, g["hit"])
+    assert np.array_equal(got, orc.aabb_batch(g["cases"]))
+
+
+@pytest.mark.parametrize("scene", TRACE_SCENES)
+def test_uploaded_tree_is_the_reference_tree(worlds, scene):
+    nodes, _ = worlds(scene).tables()
+    assert np.array_equal(nodes, golden("trace_" + scene)["topology"])
+
+
+@pytest.mark.parametrize("scene", TRACE_SCENES)
+def test_object_hit(worlds, scene):
+    g = golden("trace_" + scene)
+    w = worlds(scene)
+    for rays, tmin, tmax, exp in [(g["rays"], float(g["tmin"]), float(g["tmax"]), g["expected"]),
+                                  (g["rays2"], float(g["tmin2"]), float(g["tmax2"]), g["expected2"])]:
+        h = w.trace(rays, tmin, tmax)
+        assert np.array_equal(h["hit"], exp[:, 0].astype(np.int32))          # hit / miss
+        assert np.array_equal(h["prim"], exp[:, 1].astype(np.int32))         # object id
+        m = h["hit"] == 1
+        assert np.array_equal(h["t"][m], exp[m, 2])
+        assert np.array_equal(h["p"][m], exp[m, 3:6])
+        assert np.array_equal(h["normal"][m], exp[m, 6:9])
+
+
+def test_object_hit_random_rays_against_oracle(worlds, orc):
+    # a larger batch than the fixtures hold, incoherent, with times over the whole [-1, 1) range
+    rng = np.random.default_rng(7)
+    for scene, centre, spread in [("book2", [0, 0.5, 0], 8.0), ("stress4096", [0, 0.5, 0], 30.0), ("mixed", [0, 0.3, -1], 3.0)]:
+        n = 60000
+        o = np.array(centre) + spread * rng.uniform(-1, 1, (n, 3))
+        tgt = np.array(centre) + 0.6 * spread * rng.uniform(-1, 1, (n, 3))
+        rays = np.hstack([o, (tgt - o) * rng.uniform(0.2, 3, (n, 1)), rng.uniform(-1, 1, (n, 1))])
+        h = worlds(scene).trace(rays, 0.001, np.finfo(np.float64).max)
+        hit, prim, tpn = orc.Scene(recipe(scene)).trace(rays, 0.001, np.finfo(np.float64).max)
+        assert np.array_equal(h["hit"], hit.astype(np.int32))
+        assert np.array_equal(h["prim"], prim)
+        m = hit == 1
+        assert np.array_equal(h["t"][m], tpn[m, 0])
+        assert np.array_equal(h["p"][m], tpn[m, 1:4])
+        assert np.array_equal(h["normal"][m], tpn[m, 4:7])
+        assert 0.2 < m.mean() < 0.99
+
+
+def test_degenerate_rays(worlds, orc):
+    # zero and negative-zero direction components, a zero direction, huge and tiny scales
+    rays = np.array([
+        [0, 5, 0, 0, -1, 0, 0.5], [0, 5, 0, -0.0, -1, 0.0, 0.5], [13, 2, 3, 0, 0, 0, 0.0],
+        [0, 1, 0, 1e-300, 1e-300, 1e-300, 0.0], [0, 1, 0, 1e150, 1e150, -1e150, 0.0],
+        [4, 1, 5, 0, 0, -1, -0.99], [0, -1000, -1, 0, 1, 0, 0.0], [0, 3000, 0, 0, -1, 0, 0.0],
+    ], dtype=np.float64)
+    for scene in ["book2", "mixed"]:
+        h = worlds(scene).trace(rays, 0.001, np.finfo(np.float64).max)
+        hit, prim, tpn = orc.Scene(recipe(scene)).trace(rays, 0.001, np.finfo(np.float64).max)
+        assert np.array_equal(h["hit"], hit.astype(np.int32))
+        assert np.array_equal(h["prim"], prim)
+        m = hit == 1
+        assert np.array_equal(h["t"][m], tpn[m, 0])
+
+
+def test_empty_batches_and_bad_arguments(rt, worlds):
+    w = worlds("mixed")
+    assert len(w.trace(np.zeros((0, 7)), 0.001, 1e9)) == 0
+    assert len(w.texture(0, np.zeros((0, 3)))) == 0
+    with pytest.raises(rt.RtError, match="out of range"):
+        w.texture(999, np.zeros((1, 3)))
+    cam = rt.camera(golden("frames")["camera"])
+    with pytest.raises(rt.RtError, match="empty image"):
+        w.render(cam, 0, 4, 0, 1, 1)
+    with pytest.raises(rt.RtError, match="sample_end"):
+        w.render(cam, 4, 4, 2, 1, 1)
+    out, stats = w.render(cam, 8, 8, 5, 5, 1)   # an empty sample range renders nothing
+    assert not out.any() and stats.paths == 0
+
+
+def test_textures(worlds):
+    g = golden("texture")
+    perl = worlds("two_perlin").texture(0, g["points"])
+    assert np.array_equal(perl, g["perlin"])
+    assert perl[4000, 0] == 0.50292955069550871
+    cheq = worlds("book2").texture(2, g["points"])
+    # sin() differs from glibc's in the last bit at most; only its sign is used
+    assert np.array_equal(cheq, g["chequer"])
+
+
+@pytest.mark.parametrize("scene", ["book2", "mixed"])
+def test_scatter(worlds, scene):
+    g = golden("scatter_" + scene)
+    items, exp, k = g["items"], g["expected"], int(g["k"])
+    sc, att, out, used = worlds(scene).scatter(items[:, 0].astype(np.int32), items[:, 1:8], items[:, 8:15], exp[:, 12:12 + k])
+    assert np.array_equal(used, exp[:, 11].astype(np.int32))     # same number of draws
+    assert np.array_equal(sc, exp[:, 0].astype(np.uint8))        # scattered or absorbed
+    m = sc == 1
+    assert np.array_equal(att[m], exp[m, 1:4])
+    # lambertian and metal directions use + - * / sqrt only: bit-exact.  A dielectric's
+    # reflect/refract choice compares a uniform with schlick(), whose pow() may differ
+    # from glibc's in the last bit; both candidate directions are themselves exact.
+    assert np.array_equal(out[m], exp[m, 4:11])
+
+
+def test_scatter_reports_short_tape(rt, worlds):
+    g = golden("scatter_book2")
+    items, exp = g["items"][:64], g["expected"][:64]
+    sc, att, out, used = worlds("book2").scatter(items[:, 0].astype(np.int32), items[:, 1:8], items[:, 8:15], exp[:, 12:13])
+    need = exp[:, 11]
+    assert np.array_equal(used == -1, need > 1)
+    assert (used == -1).any()
+
+
+def test_camera_get_ray(rt):
+    g = golden("camera")
+    k = int(g["k"])
+    for cam15, exp in zip(g["cameras"], g["expected"]):
+        out, used = rt.camera_batch(rt.camera(cam15), g["st"], exp[:, 8:8 + k])
+        assert np.array_equal(used, exp[:, 7].astype(np.int32))
+        assert np.array_equal(out, exp[:, 0:7])
+
+
+FRAME_CASES = [("two_perlin", 48, 24, 6), ("book1", 64, 32, 8), ("book2", 64, 32, 8), ("mixed", 40, 40, 8), ("ties", 33, 17, 4)]
+
+
+@pytest.mark.parametrize("scene,nx,ny,ns", FRAME_CASES)
+def test_frame_matches_oracle_on_the_same_streams(rt, orc, worlds, scene, nx, ny, ns):
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = nx / ny
+    got, stats = worlds(scene).render(rt.camera(cam15), nx, ny, 0, ns, 2025, rt.RT_ACCUM_F64)
+    exp, counters = orc.Scene(recipe(scene)).render(cam15, nx, ny, 0, ns, 2025, orc.ORC_RNG_STREAM)
+    assert stats.paths == nx * ny * ns == counters.paths
+    assert stats.rays == counters.rays                      # every path took the same number of bounces
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+
+
+def test_sample_ranges_add_up(rt, worlds):
+    # what the multi-GPU split relies on: disjoint sample ranges of the same seed sum to the whole
+    cam = rt.camera(golden("frames")["camera"])
+    w = worlds("book2")
+    whole, _ = w.render(cam, 80, 40, 0, 12, 9)
+    a, _ = w.render(cam, 80, 40, 0, 5, 9)
+    b, _ = w.render(cam, 80, 40, 5, 12, 9)
+    np.testing.assert_allclose(a + b, whole, rtol=1e-13, atol=1e-13)
+    again, _ = w.render(cam, 80, 40, 0, 12, 9)
+    assert np.array_equal(whole, again)                      # deterministic
+    other, _ = w.render(cam, 80, 40, 0, 12, 10)
+    assert not np.array_equal(whole, other)                  # the seed matters
+
+
+def test_f32_accumulation_is_the_rounded_f64_sum(rt, worlds):
+    cam = rt.camera(golden("frames")["camera"])
+    w = worlds("book1")
+    f64, _ = w.render(cam, 64, 32, 0, 6, 3, rt.RT_ACCUM_F64)
+    f32, _ = w.render(cam, 64, 32, 0, 6, 3, rt.RT_ACCUM_F32)
+    assert np.array_equal(f32, f64.astype(np.float32))
+
+
+@pytest.mark.parametrize("scene", ["two_perlin", "book1", "book2"])
+def test_frame_statistics_against_reference_renders(rt, worlds, scene):
+    # The reference's frames come from one shared mt19937, the GPU's from per-path streams:
+    # the images agree as two independent Monte-Carlo estimates of the same integrand do.
+    g = golden("frames")
+    ref_a, ref_b = g[scene + "_spp256_seed1"].astype(np.float64), g[scene + "_spp256_seed2"].astype(np.float64)
+    floor = np.sqrt(np.mean((ref_a - ref_b) ** 2))          # RMSE between two reference seeds
+    sums, _ = worlds(scene).render(rt.camera(g["camera"]), 120, 60, 0, 256, 77)
+    img = sums / 256
+    for ref in (ref_a, ref_b):
+        rmse = np.sqrt(np.mean((img - ref) ** 2))
+        assert rmse <= 1.15 * floor, (rmse, floor)
+    # bias check: per-channel means within 4 sigma of the floor's standard error
+    se = floor / np.sqrt(img.shape[0] * img.shape[1]) * 4 + 1e-4
+    ref_mean = 0.5 * (ref_a + ref_b)
+    assert np.all(np.abs(img.mean(axis=(0, 1)) - ref_mean.mean(axis=(0, 1))) < se)
+    # 8-bit output as main.cpp:26-28 quantises it
+    q = lambda x: (255.99 * np.sqrt(x)).astype(int)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((q(img) - q(ref_a)) ** 2))
+    psnr_floor = 10 * np.log10(255.0 ** 2 / np.mean((q(ref_b) - q(ref_a)) ** 2))
+    assert psnr >= psnr_floor - 1.0
+
+
+def test_full_size_frame_properties(rt, worlds):
+    # BASELINE.json's size (1920x1080); the oracle cannot render it in seconds, so the
+    # checks are size-independent properties: determinism, additivity over sample
+    # ranges, bounded radiance, and agreement of the down-sampled image with the reference.
+    g = golden("frames")
+    cam15 = np.array(g["camera"])
+    cam15[10] = 1920 / 1080
+    cam = rt.camera(cam15)
+    w = worlds("book1")
+    a, sa = w.render(cam, 1920, 1080, 0, 2, 11, rt.RT_ACCUM_F64)
+    b, sb = w.render(cam, 1920, 1080, 2, 4, 11, rt.RT_ACCUM_F64)
+    ab, sab = w.render(cam, 1920, 1080, 0, 4, 11, rt.RT_ACCUM_F64)
+    np.testing.assert_allclose(a + b, ab, rtol=1e-13, atol=1e-13)
+    assert sa.rays + sb.rays == sab.rays and sab.paths == 1920 * 1080 * 4
+    assert ab.min() >= 0 and ab.max() <= 4.0 + 1e-9          # every sample's radiance is within [0, 1]
+    assert 2.0 < sab.rays / sab.paths < 4.0                  # bounces per path of this scene
+    # the 16:9 frame has the 2:1 frame's vertical field of view; compare the common centre band
+    small = ab.reshape(60, 18, 120, 16, 3).mean(axis=(1, 3)) / 4      # 120 x 60 box-filtered
+    ref = g["book1_spp256_seed1"].astype(np.float64)
+    # same vertical extent; the reference frame is wider (2.0 vs 1.78): its centre 106.7 columns
+    lo = int(round((120 - 120 * (16 / 9) / 2.0) / 2))
+    ref_c = ref[:, lo:120 - lo]
+    small_c = small[:, ::1]
+    # resample the GPU frame's 120 columns onto the reference's centre band
+    xs = np.linspace(0, 119, ref_c.shape[1])
+    res = np.stack([np.stack([np.interp(xs, np.arange(120), small_c[r, :, c]) for c in range(3)], axis=-1) for r in range(60)])
+    assert np.sqrt(np.mean((res - ref_c) ** 2)) < 0.06
+
+
+def test_resolve(rt):
+    import torch
+    sums = torch.rand(4096 * 3, device="cuda") * 8
+    out = torch.zeros(4096 * 3, dtype=torch.uint8, device="cuda")
+    rc = rt.hip().rt_resolve(0, ctypes.c_void_p(sums.data_ptr()), 4096, 8, ctypes.c_void_p(out.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    exp = (255.99 * np.sqrt(sums.cpu().numpy().astype(np.float64) / 8)).astype(int)
+    assert np.array_equal(out.cpu().numpy().astype(int), exp)

@@ -1,0 +1,119 @@
+"""Host-side checks that need no GPU: the C ABI library loads and exports what the header
+declares, the host BVH build reproduces the reference's tree, and compute calls fail
+loudly (no CPU fallback) when there is no device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TRACE_SCENES, golden, recipe
+
+
+def test_c_abi_exports_every_declared_symbol(rt):
+    header = open(os.path.join(ROOT, "include", "rtiow_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(rt.HIP_SYMBOLS)
+    lib = rt.hip()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_struct_sizes(rt):
+    # the layouts the numpy side assumes must be the header's
+    assert rt.HIT_DTYPE.itemsize == 64
+    assert ctypes.sizeof(rt.rt_camera) == 24 * 8
+    assert ctypes.sizeof(rt.rt_render_params) == 40
+    assert ctypes.sizeof(rt.rt_node_desc) == 56
+
+
+@pytest.mark.parametrize("scene", TRACE_SCENES)
+def test_host_bvh_build_matches_reference_tree(rt, scene):
+    # bvh_node's constructor on the host (random axis from mt19937, std::ranges::sort,
+    # median split) must produce the reference's tree: same children, same boxes, to the bit
+    nodes, items = rt.world_tables(recipe(scene))
+    topo = golden("trace_" + scene)["topology"]
+    assert nodes.shape == topo.shape
+    assert np.array_equal(nodes, topo)
+    assert len(items) >= 1
+
+
+def test_perlin_tables_match_reference_sequence(rt, orc):
+    for a, b in zip(rt.perlin_tables(), orc.perlin_tables()):
+        assert np.array_equal(a, b)
+    ran, px, py, pz = rt.perlin_tables()
+    assert sorted(px) == list(range(256)) and sorted(py) == list(range(256)) and sorted(pz) == list(range(256))
+
+
+def test_camera_basis_matches_reference(rt, orc):
+    g = golden("camera")
+    for cam15, exp in zip(g["cameras"], g["expected"]):
+        c = rt.camera(cam15)
+        # aperture contributes only through the lens offset; the basis itself is checked by
+        # rebuilding a ray for the tape's accepted disk sample, in the reference's order
+        k = int(g["k"])
+        st = g["st"][:64]
+        out, used = orc.camera_batch(cam15, st, exp[:64, 8:8 + k])
+        assert np.array_equal(out, exp[:64, 0:7])
+        o, u, v = np.array(c.origin), np.array(c.u), np.array(c.v)
+        llc, hz, vt = np.array(c.lower_left_corner), np.array(c.horizontal), np.array(c.vertical)
+        for i in range(64):
+            n = used[i]
+            tape = exp[i, 8:8 + n]
+            px, py = tape[n - 3] * 2 + -1, tape[n - 2] * 2 + -1
+            rd = np.array([px, py, 0.0]) * c.lens_radius
+            off = u * rd[0] + v * rd[1]
+            d = (((llc + st[i, 0] * hz) + st[i, 1] * vt) - o) - off
+            assert np.array_equal(o + off, out[i, 0:3])
+            assert np.array_equal(d, out[i, 3:6])
+            assert c.time0 + (tape[n - 1] * 2 + -1) * (c.time1 - c.time0) == out[i, 6]
+
+
+def test_recipe_errors_are_reported(rt, tmp_path):
+    bad = tmp_path / "bad.recipe"
+    bad.write_text("rtiow-recipe 1\nsphere 0 0 0 0 1\n")
+    with pytest.raises(rt.RtError, match="material out of range"):
+        rt.world_tables(str(bad))
+    with pytest.raises(rt.RtError):
+        rt.world_tables(str(tmp_path / "missing.recipe"))
+    with pytest.raises(rt.RtError, match="unknown scene kind"):
+        rt.generate("nope", 1, str(tmp_path / "x.recipe"))
+
+
+def test_generators_are_deterministic(rt, tmp_path):
+    for kind in ["two_perlin", "book1", "book2"]:
+        p = tmp_path / (kind + ".recipe")
+        rt.generate(kind, 1 if kind != "two_perlin" else 0, str(p))
+        assert p.read_text() == open(recipe(kind)).read()
+    # the static variant keeps every draw: same centres and materials as the moving one
+    b1 = [l.split() for l in open(recipe("book1")) if l.startswith(("sphere", "moving_sphere"))]
+    b2 = [l.split() for l in open(recipe("book2")) if l.startswith(("sphere", "moving_sphere"))]
+    assert len(b1) == len(b2) and 400 < len(b1) < 500
+    for s1, s2 in zip(b1[4:], b2[4:]):
+        assert s1[2:5] == s2[2:5]
+
+
+def test_compute_fails_loudly_without_a_gpu(rt):
+    if rt.hip().rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError, match="no HIP device"):
+        rt.World(recipe("mixed"))
+    with pytest.raises(rt.RtError):
+        rt.aabb_hit_batch(golden("aabb")["cases"][:4])
+
+
+def test_scene_description_is_validated(rt):
+    # validation runs before any device work, so it is observable without a GPU
+    lib = rt.hip()
+
+    class tex(ctypes.Structure):
+        _fields_ = [("kind", ctypes.c_uint32), ("even", ctypes.c_uint32), ("odd", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("colour", ctypes.c_double * 3)]
+    d = rt.rt_scene_desc()
+    t = (tex * 1)(tex(1, 0, 0, 0, (ctypes.c_double * 3)(0, 0, 0)))   # a chequer that refers to itself
+    d.textures = ctypes.cast(t, ctypes.c_void_p)
+    d.n_textures = 1
+    out = ctypes.c_void_p()
+    rc = lib.rt_scene_create(ctypes.byref(d), 0, ctypes.byref(out))
+    assert rc == 1 and b"earlier textures" in lib.rt_last_error()
+    assert lib.rt_scene_create(None, 0, ctypes.byref(out)) == 1
