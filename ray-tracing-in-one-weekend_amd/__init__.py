@@ -83,12 +83,34 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _preload_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch ships its own libamdhip64 (soname
+    libamdhip64.so.7, the name librtiow_hip.so asks for); if the system copy were loaded
+    first and torch imported later, the process would hold two runtimes and the second
+    would see no GPU.  Loading torch's copy first, when torch is installed, makes every
+    import order end with that single copy.  Torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def hip():
     """The GPU library.  Raises ImportError when it has not been built."""
     global _hip
     if _hip is None:
         if not os.path.exists(HIP_LIB):
             raise ImportError(f"{HIP_LIB} is missing: run `make -C {CSRC}` (or __graft_entry__.build())")
+        _preload_hip_runtime()
         lib = ctypes.CDLL(HIP_LIB)
         lib.rt_last_error.restype = ctypes.c_char_p
         vp, sz, dbl, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_uint32
