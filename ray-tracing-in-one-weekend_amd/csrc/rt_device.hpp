@@ -15,24 +15,32 @@
 namespace rtd {
 
 // ---------------------------------------------------------------- scene layout ----
-// One node holds the boxes of BOTH children, so a single fetch decides both descents.
-// A child that is a primitive has no box: the reference tests primitives directly
-// once their parent's box is hit (bvh_node.cpp:57-59).
+// A node of the device tree is a reference node whose children are both nodes; it holds
+// the boxes of BOTH children, so a single fetch decides both descents.  A reference node
+// whose children are primitives (bvh_node.cpp:31-37: one object twice, or two objects)
+// becomes a "leaf": its box sits in its parent's child slot like any other, and visiting
+// it means testing its one or two spheres, which are adjacent in the primitive table.
 struct __attribute__((aligned(16))) DNode {
     double bx[2][6];   // per child: min x, max x, min y, max y, min z, max z
-    int32_t child[2];  // >= 0 node index, < 0 ~primitive index (device order)
-    uint32_t flags;    // see NF_*
+    int32_t child[2];  // >= 0 node index, < 0 leaf reference (see leaf_ref)
+    uint32_t flags;    // NF_SAFE0 | NF_SAFE1
     uint32_t pad0;
     double pad1[2];
 };
 static_assert(sizeof(DNode) == 128, "DNode is two 64-byte lines");
 
-enum : uint32_t {
-    NF_MOVING0 = 1u, NF_MOVING1 = 2u,  // child is a moving sphere
-    NF_SAFE0 = 4u, NF_SAFE1 = 8u,      // every primitive under the child stays inside its box: the
-                                       // descent may be skipped once the box starts beyond the best hit
-    NF_SAME = 16u                      // both children are the same object (bvh_node.cpp:31-34)
-};
+// Every primitive under a SAFE child stays inside the child's box (static spheres), so
+// the descent may be skipped once the box starts beyond the best hit.  A moving sphere
+// leaves the box the reference gives it (moving_sphere.cpp:58): subtrees holding one are
+// always visited, as the reference visits them.
+enum : uint32_t { NF_SAFE0 = 1u, NF_SAFE1 = 2u };
+
+// leaf reference: bit 31 set; bits 0-27 first primitive (device order); bit 28: a second
+// primitive follows; bits 29, 30: first / second primitive is a moving sphere
+constexpr int32_t LEAF_BIT = (int32_t)0x80000000u;
+constexpr int32_t LEAF_TWO = 1 << 28, LEAF_MOVING0 = 1 << 29, LEAF_MOVING1 = 1 << 30;
+constexpr int32_t LEAF_INDEX_MASK = 0x0FFFFFFF;
+constexpr int32_t REF_NONE = (int32_t)0x8FFFFFFFu;   // a leaf index no scene can reach
 
 enum : uint32_t { PK_STATIC = 0, PK_MOVING = 1, PK_MOVING_UNIT = 2 };
 
@@ -44,7 +52,9 @@ struct __attribute__((aligned(16))) DPrim {
 };
 static_assert(sizeof(DPrim) == 96, "DPrim layout");
 
-struct DItem { uint32_t is_bvh; int32_t index; uint32_t moving; uint32_t pad; double box[6]; };
+// One entry of the world's object_list.  ref is a node index or a leaf reference;
+// has_box = 0 for a bare primitive in the list (object_list.cpp:18 tests it directly).
+struct DItem { int32_t ref; uint32_t has_box; uint32_t pad[2]; double box[6]; };
 struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; };
 struct DTex { uint32_t kind; uint32_t even, odd; uint32_t pad; double c[3]; };
 
@@ -205,90 +215,99 @@ __device__ __forceinline__ bool sphere_root(v3 c, double radius, const RayCtx &r
 }
 
 // ------------------------------------------------------------------ traversal ----
-// bvh_node::hit (bvh_node.cpp:52-69) for the whole tree under `root`, whose own box has
-// already been tested.  The reference visits both children of every node whose box is
-// hit, with the interval it was given, and on equal t keeps the right-hand result; that
-// is "the smallest t, and among equal t the last leaf in left-to-right order".  Leaves
-// are numbered in that order, so any visiting order gives the same answer.  A subtree
-// whose primitives cannot leave their boxes (static spheres) can only produce hits at
-// or after its box's entry point, so it is skipped when that lies beyond the best hit;
-// subtrees holding moving spheres are always visited, because the reference's boxes do
-// not bound them (moving_sphere.cpp:58).
-__device__ __forceinline__ void bvh_closest(const DScene &sc, int root, const RayCtx &r, double tmin, double tmax,
-                                            int *stack, int stride, double &best_t, int &best_prim) {
-    int sp = 0;
-    int cur = root;
-    for (;;) {
-        const DNode *nd = sc.nodes + cur;
-        const uint32_t flags = nd->flags;
-        const int c0 = nd->child[0], c1 = nd->child[1];
-        int go0 = -1, go1 = -1;
-        double e0 = 0, e1 = 0;
-        if (c0 >= 0) {
-            double bx[6];
+// bvh_node::hit (bvh_node.cpp:52-69) as a walk with an explicit stack.  The reference
+// visits both children of every node whose box is hit, with the interval it was given,
+// and on equal t keeps the right-hand result: "the smallest t, and among equal t the
+// last leaf in left-to-right order".  Primitives are numbered in that order, so any
+// visiting order gives the same answer.
+struct Trav {
+    int32_t cur;     // node index, leaf reference, or REF_NONE when the walk is over
+    int32_t sp;      // stack entries in use
+    double bt;       // best hit of the item being walked
+    int32_t bp;      // its primitive (device order), -1 = none
+};
+
+__device__ __forceinline__ int32_t trav_pop(Trav &tv, const int *stack, int stride) {
+    int32_t r = REF_NONE;
+    if (tv.sp > 0) { --tv.sp; r = stack[tv.sp * stride]; }
+    return r;
+}
+
+// One node: test both child boxes, continue with the nearer, push the farther.
+__device__ __forceinline__ void node_step(const DScene &sc, const RayCtx &r, double tmin, double tmax, int *stack,
+                                          int stride, Trav &tv) {
+    const DNode *nd = sc.nodes + tv.cur;
+    const uint32_t flags = nd->flags;
+    const int32_t c0 = nd->child[0], c1 = nd->child[1];
+    double b0[6], b1[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) bx[k] = nd->bx[0][k];
-            if (box_test(bx, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || best_prim < 0 || e0 <= best_t)) go0 = c0;
-        } else {
-            const DPrim *p = sc.prims + ~c0;
-            double t;
-            if (sphere_root(prim_centre(p, flags & NF_MOVING0, r.time), p->r, r, tmin, tmax, t)) {
-                if (best_prim < 0 || t < best_t || (t == best_t && ~c0 > best_prim)) { best_t = t; best_prim = ~c0; }
-            }
-        }
-        if (c1 >= 0) {
-            double bx[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) bx[k] = nd->bx[1][k];
-            if (box_test(bx, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || best_prim < 0 || e1 <= best_t)) go1 = c1;
-        } else if (!(flags & NF_SAME)) {
-            const DPrim *p = sc.prims + ~c1;
-            double t;
-            if (sphere_root(prim_centre(p, flags & NF_MOVING1, r.time), p->r, r, tmin, tmax, t)) {
-                if (best_prim < 0 || t < best_t || (t == best_t && ~c1 > best_prim)) { best_t = t; best_prim = ~c1; }
-            }
-        }
-        if (go0 >= 0 && go1 >= 0) {
-            const bool near0 = e0 <= e1;
-            stack[sp * stride] = near0 ? go1 : go0;
-            ++sp;
-            cur = near0 ? go0 : go1;
-        } else if (go0 >= 0) {
-            cur = go0;
-        } else if (go1 >= 0) {
-            cur = go1;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * stride];
-        }
+    for (int k = 0; k < 6; ++k) { b0[k] = nd->bx[0][k]; b1[k] = nd->bx[1][k]; }
+    double e0, e1;
+    const bool none = tv.bp < 0;
+    const bool h0 = box_test(b0, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || none || e0 <= tv.bt);
+    const bool h1 = box_test(b1, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || none || e1 <= tv.bt);
+    const bool near0 = e0 <= e1;
+    if (h0 && h1) {
+        stack[tv.sp * stride] = near0 ? c1 : c0;
+        ++tv.sp;
+        tv.cur = near0 ? c0 : c1;
+    } else if (h0 || h1) {
+        tv.cur = h0 ? c0 : c1;
+    } else {
+        tv.cur = trav_pop(tv, stack, stride);
     }
 }
 
-// object_list::hit (object_list.cpp:12-26) over the world's items: each item sees the
-// interval narrowed to the closest hit so far and replaces it only with a strictly
-// nearer one.
+__device__ __forceinline__ void leaf_candidate(const DScene &sc, int32_t prim, bool moving, const RayCtx &r,
+                                               double tmin, double tmax, Trav &tv) {
+    const DPrim *p = sc.prims + prim;
+    double t;
+    if (sphere_root(prim_centre(p, moving, r.time), p->r, r, tmin, tmax, t)) {
+        if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; }
+    }
+}
+
+// One leaf: its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the
+// next stack entry.
+__device__ __forceinline__ void leaf_step(const DScene &sc, const RayCtx &r, double tmin, double tmax, const int *stack,
+                                          int stride, Trav &tv) {
+    const int32_t ref = tv.cur;
+    const int32_t first = ref & LEAF_INDEX_MASK;
+    leaf_candidate(sc, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
+    if (ref & LEAF_TWO) leaf_candidate(sc, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    tv.cur = trav_pop(tv, stack, stride);
+}
+
+// Starts the walk of one world item: tests the root box as bvh_node::hit does first
+// (bvh_node.cpp:53).  Returns false when the item cannot be hit.
+__device__ __forceinline__ bool item_begin(const DScene &sc, uint32_t item, const RayCtx &r, double tmin, double tmax, Trav &tv) {
+    const DItem *it = sc.items + item;
+    tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.cur = REF_NONE;
+    if (it->has_box) {
+        double bx[6], entry;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bx[k] = it->box[k];
+        if (!box_test(bx, r, tmin, tmax, entry)) return false;
+    }
+    tv.cur = it->ref;
+    return true;
+}
+
+// object_list::hit (object_list.cpp:12-26) over the world's items, one ray per lane:
+// each item sees the interval narrowed to the closest hit so far and replaces it only
+// with a strictly nearer one (sphere_root's t < tmax).
 __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r, double tmin, double tmax,
                                               int *stack, int stride, double &t_out, int &prim_out) {
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
-        const DItem *it = sc.items + i;
-        if (it->is_bvh) {
-            double entry;
-            double bx[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) bx[k] = it->box[k];
-            if (!box_test(bx, r, tmin, closest, entry)) continue;
-            double bt = 0;
-            int bp = -1;
-            bvh_closest(sc, it->index, r, tmin, closest, stack, stride, bt, bp);
-            if (bp >= 0) { closest = bt; found = bp; }
-        } else {
-            const DPrim *p = sc.prims + it->index;
-            double t;
-            if (sphere_root(prim_centre(p, it->moving, r.time), p->r, r, tmin, closest, t)) { closest = t; found = it->index; }
+        Trav tv;
+        if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
+        while (tv.cur != REF_NONE) {
+            if (tv.cur >= 0) node_step(sc, r, tmin, closest, stack, stride, tv);
+            else leaf_step(sc, r, tmin, closest, stack, stride, tv);
         }
+        if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }
     t_out = closest;
     prim_out = found;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -254,7 +255,8 @@ struct flattener {
     uint32_t max_depth = 0;
     const char *error = nullptr;
 
-    int emit_prim(int32_t id, bool &moving, bool &safe) {
+    // appends a primitive; returns its leaf-reference bits for slot `second`
+    int32_t emit_prim(int32_t id, bool second, bool &safe) {
         const rt_prim_desc &p = desc->prims[id];
         DPrim d;
         memset(&d, 0, sizeof d);
@@ -262,7 +264,7 @@ struct flattener {
         d.r = p.radius; d.t0 = p.time0; d.t1 = p.time1;
         d.mat = p.material;
         d.orig = id;
-        moving = p.kind == RT_PRIM_MOVING_SPHERE;
+        const bool moving = p.kind == RT_PRIM_MOVING_SPHERE;
         if (!moving) {
             d.kind = PK_STATIC;
             for (int k = 0; k < 3; ++k) d.dc[k] = 0;
@@ -272,41 +274,51 @@ struct flattener {
         // a sphere that never moves stays inside the box the reference gives it
         safe = !moving;
         prims.push_back(d);
-        return (int)prims.size() - 1;
+        if (prims.size() >= (size_t)LEAF_INDEX_MASK) error = "more than 2^28 primitives";
+        return moving ? (second ? LEAF_MOVING1 : LEAF_MOVING0) : 0;
     }
 
-    // returns the device index of the node built for description node `id`
-    int build(int32_t id, uint32_t depth, bool &safe) {
-        if (error) return 0;
-        if (depth > 64) { error = "bvh deeper than 64 levels (or cyclic)"; return 0; }
-        if (nodes.size() > (1u << 26)) { error = "bvh larger than 2^26 nodes"; return 0; }
-        if (depth + 1 > max_depth) max_depth = depth + 1;
+    int32_t leaf_of(int32_t prim_a, int32_t prim_b, bool &safe) {
+        bool sa = true, sb = true;
+        int32_t ref = LEAF_BIT | (int32_t)prims.size();
+        ref |= emit_prim(prim_a, false, sa);
+        if (prim_b != prim_a) ref |= LEAF_TWO | emit_prim(prim_b, true, sb);
+        safe = sa && sb;
+        return ref;
+    }
+
+    // returns the device reference (node index or leaf) built for description node `id`
+    int32_t build(int32_t id, uint32_t depth, bool &safe) {
+        if (error) return REF_NONE;
+        if (depth > 64) { error = "bvh deeper than 64 levels (or cyclic)"; return REF_NONE; }
+        if (nodes.size() > (1u << 26)) { error = "bvh larger than 2^26 nodes"; return REF_NONE; }
         const rt_node_desc nd = desc->nodes[id];
+        const int32_t ref[2] = {nd.left, nd.right};
+        for (int c = 0; c < 2; ++c) {
+            if (ref[c] >= 0 ? (uint32_t)ref[c] >= desc->n_nodes : (uint32_t)~ref[c] >= desc->n_prims) {
+                error = "node child out of range";
+                return REF_NONE;
+            }
+        }
+        if (ref[0] < 0 && ref[1] < 0) return leaf_of(~ref[0], ~ref[1], safe);   // bvh_node.cpp:31-37
+
+        if (depth + 1 > max_depth) max_depth = depth + 1;
         const int me = (int)nodes.size();
         nodes.emplace_back();
         DNode out;
         memset(&out, 0, sizeof out);
         bool safe_c[2] = {true, true};
-        const int32_t ref[2] = {nd.left, nd.right};
         for (int c = 0; c < 2; ++c) {
-            if (c == 1 && ref[1] == ref[0] && ref[0] < 0) {
-                out.child[1] = out.child[0];
-                out.flags |= NF_SAME;
-                if (out.flags & NF_MOVING0) out.flags |= NF_MOVING1;
-                safe_c[1] = safe_c[0];
-                continue;
-            }
             if (ref[c] >= 0) {
-                if ((uint32_t)ref[c] >= desc->n_nodes) { error = "node child out of range"; return 0; }
                 const rt_node_desc &ch = desc->nodes[ref[c]];
                 for (int a = 0; a < 3; ++a) { out.bx[c][2 * a] = ch.box_min[a]; out.bx[c][2 * a + 1] = ch.box_max[a]; }
                 out.child[c] = build(ref[c], depth + 1, safe_c[c]);
-                if (error) return 0;
+                if (error) return REF_NONE;
             } else {
-                if ((uint32_t)~ref[c] >= desc->n_prims) { error = "node primitive out of range"; return 0; }
-                bool moving;
-                out.child[c] = ~emit_prim(~ref[c], moving, safe_c[c]);
-                if (moving) out.flags |= (c == 0 ? NF_MOVING0 : NF_MOVING1);
+                // a primitive beside a subtree: the reference tests it without a box, which
+                // an unbounded box reproduces (every slab interval is (-inf, +inf))
+                for (int a = 0; a < 3; ++a) { out.bx[c][2 * a] = -HUGE_VAL; out.bx[c][2 * a + 1] = HUGE_VAL; }
+                out.child[c] = leaf_of(~ref[c], ~ref[c], safe_c[c]);
             }
         }
         if (safe_c[0]) out.flags |= NF_SAFE0;
@@ -376,18 +388,16 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         const rt_item_desc &it = desc->items[i];
         DItem di;
         memset(&di, 0, sizeof di);
-        di.is_bvh = it.is_bvh ? 1u : 0u;
+        bool safe;
         if (it.is_bvh) {
             const rt_node_desc &root = desc->nodes[it.index];
             for (int a = 0; a < 3; ++a) { di.box[2 * a] = root.box_min[a]; di.box[2 * a + 1] = root.box_max[a]; }
-            bool safe;
-            di.index = fl.build(it.index, 0, safe);
-            if (fl.error) return fail(RT_E_UNSUPPORTED, "%s", fl.error);
+            di.has_box = 1;
+            di.ref = fl.build(it.index, 0, safe);
         } else {
-            bool moving, safe;
-            di.index = fl.emit_prim(it.index, moving, safe);
-            di.moving = moving ? 1u : 0u;
+            di.ref = fl.leaf_of(it.index, it.index, safe);
         }
+        if (fl.error) return fail(RT_E_UNSUPPORTED, "%s", fl.error);
         items.push_back(di);
     }
 
