@@ -21,7 +21,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-HIP_LIB = os.path.join(CSRC, "librtiow_hip.so")
+HIP_LIB = os.environ.get("RTIOW_HIP_LIB", os.path.join(CSRC, "librtiow_hip.so"))   # override: A/B builds during tuning
 HOST_LIB = os.path.join(CSRC, "librtiow_host.so")
 
 RT_ACCUM_F32, RT_ACCUM_F64 = 0, 1
@@ -111,7 +111,8 @@ def hip():
         if not os.path.exists(HIP_LIB):
             raise ImportError(f"{HIP_LIB} is missing: run `make -C {CSRC}` (or __graft_entry__.build())")
         _preload_hip_runtime()
-        lib = ctypes.CDLL(HIP_LIB)
+        # global scope, so that librtiow_host.so binds to this copy whichever path it came from
+        lib = ctypes.CDLL(HIP_LIB, mode=ctypes.RTLD_GLOBAL)
         lib.rt_last_error.restype = ctypes.c_char_p
         vp, sz, dbl, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_uint32
         lib.rt_trace_batch.argtypes = [vp, vp, sz, dbl, dbl, vp]

@@ -314,6 +314,36 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
     return found >= 0;
 }
 
+// The same walk for a whole wave that traces together.  Node steps outnumber leaf steps
+// about eight to one, so letting both bodies run in every iteration would execute the
+// sphere code for a handful of lanes each time.  Instead the wave counts, per iteration,
+// how many of its walking lanes stand at a leaf: the leaf body runs only when at least
+// LEAF_QUORUM lanes wait for it (or nobody wants a node); otherwise the node body runs.
+template <int LEAF_QUORUM>
+__device__ __forceinline__ bool world_closest_voted(const DScene &sc, const RayCtx &r, double tmin, double tmax,
+                                                    int *stack, int stride, double &t_out, int &prim_out) {
+    double closest = tmax;
+    int found = -1;
+    for (uint32_t i = 0; i < sc.n_items; ++i) {
+        Trav tv;
+        if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
+        while (tv.cur != REF_NONE) {
+            const bool at_node = tv.cur >= 0;
+            const int n_node = __popcll(__ballot(at_node));
+            const int n_leaf = __popcll(__ballot(!at_node));
+            if (n_leaf >= LEAF_QUORUM || n_node == 0) {
+                if (!at_node) leaf_step(sc, r, tmin, closest, stack, stride, tv);
+            } else {
+                if (at_node) node_step(sc, r, tmin, closest, stack, stride, tv);
+            }
+        }
+        if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
+    }
+    t_out = closest;
+    prim_out = found;
+    return found >= 0;
+}
+
 // hit_record of the winning primitive (sphere.cpp:23-29): p = o + t d, n = (p - c) / r
 __device__ __forceinline__ void hit_point(const DScene &sc, int prim, const RayCtx &r, double t, v3 &p, v3 &n) {
     const DPrim *pr = sc.prims + prim;

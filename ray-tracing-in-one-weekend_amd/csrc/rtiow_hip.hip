@@ -112,26 +112,40 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 }
 
 // The pixel/sample loop (main.cpp:126-141) with ray_colour (main.cpp:30-50) unrolled
-// into one loop over ray segments.  A lane owns one pixel and walks its samples in
-// order; as soon as a path ends the lane starts its next sample, so the lanes of a wave
-// stay busy at different bounce depths instead of waiting for the longest path.
-// Block = 16x16 pixels, wave = 8x8 pixels.
-template <class AccT>
-__global__ __launch_bounds__(kBlock) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
-                                                  uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
-                                                  AccT *accum, unsigned long long *ray_count) {
-    extern __shared__ int lds_stack[];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const uint32_t y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < nx && y < ny;
-    const uint32_t pix = y * nx + x;
-    const uint32_t j = ny - 1 - y;  // the reference's row index runs bottom-up (main.cpp:126)
-    int *stack = lds_stack + tid;
+// into one loop over ray segments.
+//
+// A wave owns an 8x8 pixel tile and the 64 x (s_end - s_begin) paths through it.  Paths
+// are numbered k = sample * 64 + pixel-in-tile; a lane whose path has ended claims the
+// next unclaimed k (lanes that claim together take consecutive numbers), so every lane
+// stays busy until the tile's paths run out, whatever the mix of short sky paths and
+// long glass paths in the tile.  A finished path adds its radiance to the tile's sums in
+// LDS; the random stream is keyed by (pixel, sample), so the set of paths -- and every
+// path's arithmetic -- is independent of which lane ran it.
+#ifndef RT_RENDER_WAVES
+#define RT_RENDER_WAVES 3
+#endif
+#ifndef RT_LEAF_QUORUM
+#define RT_LEAF_QUORUM 8
+#endif
 
-    uint32_t s = inside ? s_begin : s_end;
+template <class AccT>
+__global__ __launch_bounds__(kBlock, RT_RENDER_WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny,
+                                                                   uint32_t s_begin, uint32_t s_end, uint32_t max_depth,
+                                                                   double t_min, uint64_t seed, AccT *accum,
+                                                                   unsigned long long *ray_count) {
+    extern __shared__ int lds_raw[];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // LDS: per-wave radiance sums (64 pixels x rgb, doubles) first, then the traversal stacks
+    double *tile_sum = reinterpret_cast<double *>(lds_raw) + wave * 192;
+    int *stack = lds_raw + (kBlock / 64) * 192 * 2 + tid;
+    tile_sum[lane] = 0; tile_sum[64 + lane] = 0; tile_sum[128 + lane] = 0;
+
+    const uint32_t tile_x = blockIdx.x * 16 + (wave & 1) * 8, tile_y = blockIdx.y * 16 + (wave >> 1) * 8;
+    const uint32_t total = (tile_x < nx && tile_y < ny) ? 64u * (s_end - s_begin) : 0u;
+    uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
+
     bool alive = false;
-    double sr = 0, sg = 0, sb = 0;
+    uint32_t slot = 0;   // pixel-in-tile of the lane's current path
     Ray r = {mk(0, 0, 0), mk(0, 0, 1), 0};
     v3 thr = mk(1, 1, 1);
     uint32_t depth = 0;
@@ -139,46 +153,67 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, DCamera cam, uint3
     StreamRng g = {1, 0, 0, 0};
 
     for (;;) {
-        if (!alive && s < s_end) {
-            g.init(seed, pix, s);
-            const double ii = (double)x + uniform(g, 0.0, 1.0);
-            const double jj = (double)j + uniform(g, 0.0, 1.0);
-            const double u = ii / (double)nx, v = jj / (double)ny;
-            r = camera_ray(cam, u, v, g);
-            thr = mk(1, 1, 1);
-            depth = 0;
-            alive = true;
-            ++s;
+        // lanes without a path claim the next unclaimed ones, in lane order
+        const unsigned long long want = __ballot(!alive);
+        if (want != 0 && next < total) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            const uint32_t k = next + rank;
+            const uint32_t claimed = (uint32_t)__popcll(want);
+            next = (total - next > claimed) ? next + claimed : total;
+            if (!alive && k < total) {
+                slot = k & 63u;
+                const uint32_t x = tile_x + (slot & 7u), y = tile_y + (slot >> 3);
+                if (x < nx && y < ny) {
+                    const uint32_t smp = s_begin + (k >> 6);
+                    g.init(seed, y * nx + x, smp);
+                    // the reference's row index runs bottom-up (main.cpp:126)
+                    const double ii = (double)x + uniform(g, 0.0, 1.0);
+                    const double jj = (double)(ny - 1 - y) + uniform(g, 0.0, 1.0);
+                    const double u = ii / (double)nx, v = jj / (double)ny;
+                    r = camera_ray(cam, u, v, g);
+                    thr = mk(1, 1, 1);
+                    depth = 0;
+                    alive = true;
+                }
+            }
         }
-        if (!__any(alive)) break;
+        if (!__any(alive)) {
+            if (next >= total) break;
+            continue;
+        }
         if (alive) {
             const RayCtx ctx = make_ctx(r);
             double t;
             int prim;
             ++nrays;
-            if (world_closest(sc, ctx, t_min, DBL_MAX, stack, kBlock, t, prim)) {
+            if (world_closest_voted<RT_LEAF_QUORUM>(sc, ctx, t_min, DBL_MAX, stack, kBlock, t, prim)) {
                 v3 p, nn, att;
-                Ray next;
+                Ray nextray;
                 hit_point(sc, prim, ctx, t, p, nn);
                 // scatter first, depth test second (main.cpp:33-34)
-                const bool ok = scatter(sc, sc.prims[prim].mat, r, p, nn, g, att, next);
+                const bool ok = scatter(sc, sc.prims[prim].mat, r, p, nn, g, att, nextray);
                 if (depth < max_depth && ok) {
                     thr = mk(thr.x * att.x, thr.y * att.y, thr.z * att.z);
-                    r = next;
+                    r = nextray;
                     ++depth;
                 } else {
                     alive = false;  // absorbed or too deep: black (main.cpp:42)
                 }
             } else {
                 const v3 c = sky(r.d);
-                sr += c.x * thr.x; sg += c.y * thr.y; sb += c.z * thr.z;
+                __hip_atomic_fetch_add(tile_sum + slot, c.x * thr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(tile_sum + 64 + slot, c.y * thr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(tile_sum + 128 + slot, c.z * thr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 alive = false;
             }
         }
     }
-    if (inside) {
-        AccT *a = accum + (size_t)pix * 3;
-        a[0] += (AccT)sr; a[1] += (AccT)sg; a[2] += (AccT)sb;
+    {
+        const uint32_t x = tile_x + (lane & 7u), y = tile_y + (lane >> 3);
+        if (x < nx && y < ny) {
+            AccT *a = accum + ((size_t)y * nx + x) * 3;
+            a[0] += (AccT)tile_sum[lane]; a[1] += (AccT)tile_sum[64 + lane]; a[2] += (AccT)tile_sum[128 + lane];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
@@ -243,7 +278,7 @@ struct rt_scene {
     dev_buf<unsigned long long> counter;
     std::vector<uint32_t> material_of_prim;  // by description index
     uint32_t n_prims_desc = 0, n_textures = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, render_lds_bytes = 0;
 };
 
 namespace {
@@ -454,6 +489,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = fl.max_depth + 2;
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);
+    s->render_lds_bytes = s->lds_bytes + (kBlock / 64) * 192 * sizeof(double);
     *out = s;
     return RT_OK;
 }
@@ -602,10 +638,10 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     DCamera cam = to_dcamera(camera);
     unsigned long long *counter = stats ? scene->counter.p : nullptr;
     if (pr->accum_type == RT_ACCUM_F32)
-        hipLaunchKernelGGL(k_render<float>, grid, block, scene->lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
+        hipLaunchKernelGGL(k_render<float>, grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
                            pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (float *)accum_dev, counter);
     else
-        hipLaunchKernelGGL(k_render<double>, grid, block, scene->lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
+        hipLaunchKernelGGL(k_render<double>, grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
                            pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (double *)accum_dev, counter);
     HIP_TRY(hipGetLastError());
     if (stats) {
