@@ -95,7 +95,9 @@ struct RayCtx {
     v3 o, d;
     double time;
     double ix, iy, iz;   // 1/d per axis (aabb.cpp:12,27,42)
-    bool sx, sy, sz;     // 1/d < 0 -> the slab's two planes swap (aabb.cpp:16-18)
+    // 1/d < 0 -> the slab's two planes swap (aabb.cpp:16-18).  Kept as the byte offset of
+    // the plane the ray meets first inside a (min, max) pair: 0 or 8.
+    uint32_t nx8, ny8, nz8;
     double a;            // d.d (sphere.cpp:14)
 };
 
@@ -103,7 +105,7 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
     RayCtx c;
     c.o = r.o; c.d = r.d; c.time = r.time;
     c.ix = 1.0 / r.d.x; c.iy = 1.0 / r.d.y; c.iz = 1.0 / r.d.z;
-    c.sx = c.ix < 0; c.sy = c.iy < 0; c.sz = c.iz < 0;
+    c.nx8 = c.ix < 0 ? 8u : 0u; c.ny8 = c.iy < 0 ? 8u : 0u; c.nz8 = c.iz < 0 ? 8u : 0u;
     c.a = vdot(r.d, r.d);
     return c;
 }
@@ -173,14 +175,31 @@ template <class R> __device__ __forceinline__ double uniform(R &g, double a, dou
 // once after the third axis decides exactly as the reference's three early exits do.
 __device__ __forceinline__ bool box_test(const double *b, const RayCtx &r, double tmin, double tmax, double &entry) {
     double t0 = (b[0] - r.o.x) * r.ix, t1 = (b[1] - r.o.x) * r.ix;
-    tmin = __builtin_fmax(r.sx ? t1 : t0, tmin);
-    tmax = __builtin_fmin(r.sx ? t0 : t1, tmax);
+    tmin = __builtin_fmax(r.nx8 ? t1 : t0, tmin);
+    tmax = __builtin_fmin(r.nx8 ? t0 : t1, tmax);
     t0 = (b[2] - r.o.y) * r.iy; t1 = (b[3] - r.o.y) * r.iy;
-    tmin = __builtin_fmax(r.sy ? t1 : t0, tmin);
-    tmax = __builtin_fmin(r.sy ? t0 : t1, tmax);
+    tmin = __builtin_fmax(r.ny8 ? t1 : t0, tmin);
+    tmax = __builtin_fmin(r.ny8 ? t0 : t1, tmax);
     t0 = (b[4] - r.o.z) * r.iz; t1 = (b[5] - r.o.z) * r.iz;
-    tmin = __builtin_fmax(r.sz ? t1 : t0, tmin);
-    tmax = __builtin_fmin(r.sz ? t0 : t1, tmax);
+    tmin = __builtin_fmax(r.nz8 ? t1 : t0, tmin);
+    tmax = __builtin_fmin(r.nz8 ? t0 : t1, tmax);
+    entry = tmin;
+    return !(tmax <= tmin);
+}
+
+// The same test reading each slab's two planes in the order the ray meets them: the
+// swap of aabb.cpp:16-18 becomes a choice of address, which costs nothing when every
+// lane reads its own node anyway (LDS-resident tree).
+__device__ __forceinline__ bool box_test_ordered(const char *b, const RayCtx &r, double tmin, double tmax, double &entry) {
+    const double x0 = *reinterpret_cast<const double *>(b + r.nx8), x1 = *reinterpret_cast<const double *>(b + (r.nx8 ^ 8u));
+    const double y0 = *reinterpret_cast<const double *>(b + 16 + r.ny8), y1 = *reinterpret_cast<const double *>(b + 16 + (r.ny8 ^ 8u));
+    const double z0 = *reinterpret_cast<const double *>(b + 32 + r.nz8), z1 = *reinterpret_cast<const double *>(b + 32 + (r.nz8 ^ 8u));
+    tmin = __builtin_fmax((x0 - r.o.x) * r.ix, tmin);
+    tmax = __builtin_fmin((x1 - r.o.x) * r.ix, tmax);
+    tmin = __builtin_fmax((y0 - r.o.y) * r.iy, tmin);
+    tmax = __builtin_fmin((y1 - r.o.y) * r.iy, tmax);
+    tmin = __builtin_fmax((z0 - r.o.z) * r.iz, tmin);
+    tmax = __builtin_fmin((z1 - r.o.z) * r.iz, tmax);
     entry = tmin;
     return !(tmax <= tmin);
 }
@@ -258,6 +277,47 @@ __device__ __forceinline__ void node_step(const DScene &sc, const RayCtx &r, dou
     }
 }
 
+// Records of the LDS copy of the tree.  The strides are chosen so that lanes reading the
+// same field of different records spread over the banks: 120 B = 30 dwords and
+// 88 B = 22 dwords share only a factor 2 with the 64 banks, which a 64-bit read covers.
+constexpr uint32_t LNODE_STRIDE = 120;   // bx[2][6] | child[2] | flags | pad
+constexpr uint32_t LPRIM_STRIDE = 88;    // c0[3] r dc[3] t0 t1 | mat kind orig pad
+
+// Where a walk finds the tree: device memory, or the block's LDS copy.
+struct TreeView {
+    const DNode *nodes;     // device memory
+    const DPrim *prims;
+    const char *lnodes;     // LDS copies (null when the tree does not fit)
+    const char *lprims;
+};
+
+__device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, bool h1, double e0, double e1, int *stack,
+                                            int stride, Trav &tv) {
+    const bool near0 = e0 <= e1;
+    if (h0 && h1) {
+        stack[tv.sp * stride] = near0 ? c1 : c0;
+        ++tv.sp;
+        tv.cur = near0 ? c0 : c1;
+    } else if (h0 || h1) {
+        tv.cur = h0 ? c0 : c1;
+    } else {
+        tv.cur = trav_pop(tv, stack, stride);
+    }
+}
+
+// node_step on the LDS copy
+__device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &r, double tmin, double tmax, int *stack,
+                                              int stride, Trav &tv) {
+    const char *nd = lnodes + (uint32_t)tv.cur * LNODE_STRIDE;
+    const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 96), c1 = *reinterpret_cast<const int32_t *>(nd + 100);
+    const uint32_t flags = *reinterpret_cast<const uint32_t *>(nd + 104);
+    double e0, e1;
+    const bool none = tv.bp < 0;
+    const bool h0 = box_test_ordered(nd, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || none || e0 <= tv.bt);
+    const bool h1 = box_test_ordered(nd + 48, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || none || e1 <= tv.bt);
+    node_decide(c0, c1, h0, h1, e0, e1, stack, stride, tv);
+}
+
 __device__ __forceinline__ void leaf_candidate(const DScene &sc, int32_t prim, bool moving, const RayCtx &r,
                                                double tmin, double tmax, Trav &tv) {
     const DPrim *p = sc.prims + prim;
@@ -265,6 +325,31 @@ __device__ __forceinline__ void leaf_candidate(const DScene &sc, int32_t prim, b
     if (sphere_root(prim_centre(p, moving, r.time), p->r, r, tmin, tmax, t)) {
         if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; }
     }
+}
+
+__device__ __forceinline__ void leaf_candidate_lds(const char *lprims, int32_t prim, bool moving, const RayCtx &r,
+                                                   double tmin, double tmax, Trav &tv) {
+    const double *p = reinterpret_cast<const double *>(lprims + (uint32_t)prim * LPRIM_STRIDE);
+    v3 c = mk(p[0], p[1], p[2]);
+    const double radius = p[3];
+    if (moving) {
+        const uint32_t kind = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p) + 76);
+        const double s = (kind == PK_MOVING_UNIT) ? r.time : (r.time - p[7]) / (p[8] - p[7]);
+        c = vadd(c, vmul(mk(p[4], p[5], p[6]), s));
+    }
+    double t;
+    if (sphere_root(c, radius, r, tmin, tmax, t)) {
+        if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; }
+    }
+}
+
+__device__ __forceinline__ void leaf_step_lds(const char *lprims, const RayCtx &r, double tmin, double tmax, const int *stack,
+                                              int stride, Trav &tv) {
+    const int32_t ref = tv.cur;
+    const int32_t first = ref & LEAF_INDEX_MASK;
+    leaf_candidate_lds(lprims, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
+    if (ref & LEAF_TWO) leaf_candidate_lds(lprims, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    tv.cur = trav_pop(tv, stack, stride);
 }
 
 // One leaf: its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the
@@ -319,9 +404,9 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 // sphere code for a handful of lanes each time.  Instead the wave counts, per iteration,
 // how many of its walking lanes stand at a leaf: the leaf body runs only when at least
 // LEAF_QUORUM lanes wait for it (or nobody wants a node); otherwise the node body runs.
-template <int LEAF_QUORUM>
-__device__ __forceinline__ bool world_closest_voted(const DScene &sc, const RayCtx &r, double tmin, double tmax,
-                                                    int *stack, int stride, double &t_out, int &prim_out) {
+template <int LEAF_QUORUM, bool LDS_TREE>
+__device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
+                                                    double tmax, int *stack, int stride, double &t_out, int &prim_out) {
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
@@ -332,9 +417,15 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const RayC
             const int n_node = __popcll(__ballot(at_node));
             const int n_leaf = __popcll(__ballot(!at_node));
             if (n_leaf >= LEAF_QUORUM || n_node == 0) {
-                if (!at_node) leaf_step(sc, r, tmin, closest, stack, stride, tv);
+                if (!at_node) {
+                    if (LDS_TREE) leaf_step_lds(tree.lprims, r, tmin, closest, stack, stride, tv);
+                    else leaf_step(sc, r, tmin, closest, stack, stride, tv);
+                }
             } else {
-                if (at_node) node_step(sc, r, tmin, closest, stack, stride, tv);
+                if (at_node) {
+                    if (LDS_TREE) node_step_lds(tree.lnodes, r, tmin, closest, stack, stride, tv);
+                    else node_step(sc, r, tmin, closest, stack, stride, tv);
+                }
             }
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -24,7 +25,8 @@ using namespace rtd;
 // ------------------------------------------------------------------- kernels ----
 namespace {
 
-constexpr int kBlock = 256;  // 4 waves; the render kernel maps them to a 16x16 pixel tile
+constexpr int kBlock = 256;                 // batch kernels
+constexpr size_t kLdsBudget = 160 * 1024;   // LDS per CU on gfx950; the render kernel runs one block per CU
 
 __device__ __forceinline__ Ray load_ray(const rt_ray *r) {
     Ray o;
@@ -114,101 +116,131 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // The pixel/sample loop (main.cpp:126-141) with ray_colour (main.cpp:30-50) unrolled
 // into one loop over ray segments.
 //
-// A wave owns an 8x8 pixel tile and the 64 x (s_end - s_begin) paths through it.  Paths
-// are numbered k = sample * 64 + pixel-in-tile; a lane whose path has ended claims the
-// next unclaimed k (lanes that claim together take consecutive numbers), so every lane
-// stays busy until the tile's paths run out, whatever the mix of short sky paths and
-// long glass paths in the tile.  A finished path adds its radiance to the tile's sums in
-// LDS; the random stream is keyed by (pixel, sample), so the set of paths -- and every
-// path's arithmetic -- is independent of which lane ran it.
+// Persistent blocks: the grid is one block per CU; each wave draws 8x8 pixel tiles from
+// a device-wide queue until the frame is done, so no CU idles behind a slow tile.  When
+// the tree fits, the block first copies it into LDS (nodes and spheres, re-strided
+// against bank conflicts) and every traversal step reads LDS instead of the vector cache.
+//
+// A wave owns its tile's 64 x (s_end - s_begin) paths, numbered k = sample * 64 +
+// pixel-in-tile; a lane whose path has ended claims the next unclaimed k (lanes that
+// claim together take consecutive numbers), so every lane stays busy until the tile's
+// paths run out, whatever the mix of short sky paths and long glass paths in the tile.
+// A finished path adds its radiance to the tile's sums in LDS; the random stream is
+// keyed by (pixel, sample), so the set of paths -- and every path's arithmetic -- is
+// independent of which lane ran it.
 #ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 3
+#define RT_RENDER_WAVES 3          // waves per SIMD the kernel is compiled for
 #endif
 #ifndef RT_LEAF_QUORUM
-#define RT_LEAF_QUORUM 8
+#define RT_LEAF_QUORUM 4
 #endif
+constexpr int kRenderBlock = 256 * RT_RENDER_WAVES;   // one block fills a CU
+constexpr int kRenderWaves = kRenderBlock / 64;
 
-template <class AccT>
-__global__ __launch_bounds__(kBlock, RT_RENDER_WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny,
-                                                                   uint32_t s_begin, uint32_t s_end, uint32_t max_depth,
-                                                                   double t_min, uint64_t seed, AccT *accum,
-                                                                   unsigned long long *ray_count) {
-    extern __shared__ int lds_raw[];
+template <class AccT, bool LDS_TREE>
+__global__ __launch_bounds__(kRenderBlock) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
+                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
+                                                        AccT *accum, unsigned long long *counters, uint32_t n_nodes,
+                                                        uint32_t n_prims) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // LDS: per-wave radiance sums (64 pixels x rgb, doubles) first, then the traversal stacks
+    // LDS: [tile sums: waves x 64 px x rgb doubles][stacks: depth x block ints][tree copy]
     double *tile_sum = reinterpret_cast<double *>(lds_raw) + wave * 192;
-    int *stack = lds_raw + (kBlock / 64) * 192 * 2 + tid;
-    tile_sum[lane] = 0; tile_sum[64 + lane] = 0; tile_sum[128 + lane] = 0;
+    int *stack = reinterpret_cast<int *>(lds_raw + kRenderWaves * 192 * sizeof(double)) + tid;
+    char *ltree = lds_raw + kRenderWaves * 192 * sizeof(double) + (size_t)sc.stack_depth * kRenderBlock * sizeof(int);
+    TreeView tree = {sc.nodes, sc.prims, nullptr, nullptr};
+    if (LDS_TREE) {
+        char *lnodes = ltree, *lprims = ltree + (size_t)n_nodes * LNODE_STRIDE;
+        for (uint32_t i = tid; i < n_nodes * 15u; i += kRenderBlock) {   // 15 doubles of a node record are copied
+            const uint32_t n = i / 15u, w = i % 15u;
+            const double *src = reinterpret_cast<const double *>(sc.nodes + n);
+            reinterpret_cast<double *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = src[w];
+        }
+        for (uint32_t i = tid; i < n_prims * 11u; i += kRenderBlock) {   // 11 doubles of a sphere record
+            const uint32_t n = i / 11u, w = i % 11u;
+            const double *src = reinterpret_cast<const double *>(sc.prims + n);
+            reinterpret_cast<double *>(lprims + (size_t)n * LPRIM_STRIDE)[w] = src[w];
+        }
+        tree.lnodes = lnodes; tree.lprims = lprims;
+        __syncthreads();
+    }
 
-    const uint32_t tile_x = blockIdx.x * 16 + (wave & 1) * 8, tile_y = blockIdx.y * 16 + (wave >> 1) * 8;
-    const uint32_t total = (tile_x < nx && tile_y < ny) ? 64u * (s_end - s_begin) : 0u;
-    uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
-
-    bool alive = false;
-    uint32_t slot = 0;   // pixel-in-tile of the lane's current path
-    Ray r = {mk(0, 0, 0), mk(0, 0, 1), 0};
-    v3 thr = mk(1, 1, 1);
-    uint32_t depth = 0;
+    const uint32_t tiles_x = (nx + 7) / 8, tiles_y = (ny + 7) / 8, n_tiles = tiles_x * tiles_y;
     unsigned long long nrays = 0;
-    StreamRng g = {1, 0, 0, 0};
 
     for (;;) {
-        // lanes without a path claim the next unclaimed ones, in lane order
-        const unsigned long long want = __ballot(!alive);
-        if (want != 0 && next < total) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-            const uint32_t k = next + rank;
-            const uint32_t claimed = (uint32_t)__popcll(want);
-            next = (total - next > claimed) ? next + claimed : total;
-            if (!alive && k < total) {
-                slot = k & 63u;
-                const uint32_t x = tile_x + (slot & 7u), y = tile_y + (slot >> 3);
-                if (x < nx && y < ny) {
-                    const uint32_t smp = s_begin + (k >> 6);
-                    g.init(seed, y * nx + x, smp);
-                    // the reference's row index runs bottom-up (main.cpp:126)
-                    const double ii = (double)x + uniform(g, 0.0, 1.0);
-                    const double jj = (double)(ny - 1 - y) + uniform(g, 0.0, 1.0);
-                    const double u = ii / (double)nx, v = jj / (double)ny;
-                    r = camera_ray(cam, u, v, g);
-                    thr = mk(1, 1, 1);
-                    depth = 0;
-                    alive = true;
+        uint32_t tile = 0;
+        if (lane == 0) tile = (uint32_t)atomicAdd(counters + 1, 1ull);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= n_tiles) break;
+        const uint32_t tile_x = (tile % tiles_x) * 8, tile_y = (tile / tiles_x) * 8;
+        const uint32_t total = 64u * (s_end - s_begin);
+        uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
+        tile_sum[lane] = 0; tile_sum[64 + lane] = 0; tile_sum[128 + lane] = 0;
+
+        bool alive = false;
+        uint32_t slot = 0;   // pixel-in-tile of the lane's current path
+        Ray r = {mk(0, 0, 0), mk(0, 0, 1), 0};
+        v3 thr = mk(1, 1, 1);
+        uint32_t depth = 0;
+        StreamRng g = {1, 0, 0, 0};
+
+        for (;;) {
+            // lanes without a path claim the next unclaimed ones, in lane order
+            const unsigned long long want = __ballot(!alive);
+            if (want != 0 && next < total) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                const uint32_t k = next + rank;
+                const uint32_t claimed = (uint32_t)__popcll(want);
+                next = (total - next > claimed) ? next + claimed : total;
+                if (!alive && k < total) {
+                    slot = k & 63u;
+                    const uint32_t x = tile_x + (slot & 7u), y = tile_y + (slot >> 3);
+                    if (x < nx && y < ny) {
+                        const uint32_t smp = s_begin + (k >> 6);
+                        g.init(seed, y * nx + x, smp);
+                        // the reference's row index runs bottom-up (main.cpp:126)
+                        const double ii = (double)x + uniform(g, 0.0, 1.0);
+                        const double jj = (double)(ny - 1 - y) + uniform(g, 0.0, 1.0);
+                        const double u = ii / (double)nx, v = jj / (double)ny;
+                        r = camera_ray(cam, u, v, g);
+                        thr = mk(1, 1, 1);
+                        depth = 0;
+                        alive = true;
+                    }
                 }
             }
-        }
-        if (!__any(alive)) {
-            if (next >= total) break;
-            continue;
-        }
-        if (alive) {
-            const RayCtx ctx = make_ctx(r);
-            double t;
-            int prim;
-            ++nrays;
-            if (world_closest_voted<RT_LEAF_QUORUM>(sc, ctx, t_min, DBL_MAX, stack, kBlock, t, prim)) {
-                v3 p, nn, att;
-                Ray nextray;
-                hit_point(sc, prim, ctx, t, p, nn);
-                // scatter first, depth test second (main.cpp:33-34)
-                const bool ok = scatter(sc, sc.prims[prim].mat, r, p, nn, g, att, nextray);
-                if (depth < max_depth && ok) {
-                    thr = mk(thr.x * att.x, thr.y * att.y, thr.z * att.z);
-                    r = nextray;
-                    ++depth;
+            if (!__any(alive)) {
+                if (next >= total) break;
+                continue;
+            }
+            if (alive) {
+                const RayCtx ctx = make_ctx(r);
+                double t;
+                int prim;
+                ++nrays;
+                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE>(sc, tree, ctx, t_min, DBL_MAX, stack, kRenderBlock, t, prim)) {
+                    v3 p, nn, att;
+                    Ray nextray;
+                    hit_point(sc, prim, ctx, t, p, nn);
+                    // scatter first, depth test second (main.cpp:33-34)
+                    const bool ok = scatter(sc, sc.prims[prim].mat, r, p, nn, g, att, nextray);
+                    if (depth < max_depth && ok) {
+                        thr = mk(thr.x * att.x, thr.y * att.y, thr.z * att.z);
+                        r = nextray;
+                        ++depth;
+                    } else {
+                        alive = false;  // absorbed or too deep: black (main.cpp:42)
+                    }
                 } else {
-                    alive = false;  // absorbed or too deep: black (main.cpp:42)
+                    const v3 c = sky(r.d);
+                    __hip_atomic_fetch_add(tile_sum + slot, c.x * thr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(tile_sum + 64 + slot, c.y * thr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(tile_sum + 128 + slot, c.z * thr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    alive = false;
                 }
-            } else {
-                const v3 c = sky(r.d);
-                __hip_atomic_fetch_add(tile_sum + slot, c.x * thr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(tile_sum + 64 + slot, c.y * thr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(tile_sum + 128 + slot, c.z * thr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                alive = false;
             }
         }
-    }
-    {
         const uint32_t x = tile_x + (lane & 7u), y = tile_y + (lane >> 3);
         if (x < nx && y < ny) {
             AccT *a = accum + ((size_t)y * nx + x) * 3;
@@ -217,7 +249,7 @@ __global__ __launch_bounds__(kBlock, RT_RENDER_WAVES) void k_render(DScene sc, D
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
-    if (lane == 0 && ray_count) atomicAdd(ray_count, nrays);
+    if (lane == 0) atomicAdd(counters, nrays);
 }
 
 // supersampler::value, gamma2, convert (supersampler.cpp:12-19, colour.cpp:19-21, main.cpp:26-28)
@@ -278,7 +310,9 @@ struct rt_scene {
     dev_buf<unsigned long long> counter;
     std::vector<uint32_t> material_of_prim;  // by description index
     uint32_t n_prims_desc = 0, n_textures = 0;
-    size_t lds_bytes = 0, render_lds_bytes = 0;
+    size_t lds_bytes = 0, render_lds_bytes = 0, render_lds_tree_bytes = 0;
+    uint32_t n_nodes_dev = 0, n_prims_dev = 0;
+    int n_cus = 256;
 };
 
 namespace {
@@ -479,7 +513,12 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->texs.upload(texs.data(), texs.size());
     if (e == hipSuccess) e = s->ranfloat.upload(ranfloat.data(), ranfloat.size());
     if (e == hipSuccess) e = s->perm.upload(perm.data(), perm.size());
-    if (e == hipSuccess) e = s->counter.alloc(1);
+    if (e == hipSuccess) e = s->counter.alloc(2);
+    // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) {
         delete s;
         return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
@@ -489,7 +528,14 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = fl.max_depth + 2;
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);
-    s->render_lds_bytes = s->lds_bytes + (kBlock / 64) * 192 * sizeof(double);
+    s->n_nodes_dev = (uint32_t)fl.nodes.size();
+    s->n_prims_dev = (uint32_t)fl.prims.size();
+    s->render_lds_bytes = (size_t)s->d.stack_depth * kRenderBlock * sizeof(int) + kRenderWaves * 192 * sizeof(double);
+    s->render_lds_tree_bytes = s->render_lds_bytes + (size_t)s->n_nodes_dev * LNODE_STRIDE + (size_t)s->n_prims_dev * LPRIM_STRIDE;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
+    }
     *out = s;
     return RT_OK;
 }
@@ -628,21 +674,27 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // counters[0] = rays traced, counters[1] = next tile of the frame
+    HIP_TRY(hipMemsetAsync(scene->counter.p, 0, 2 * sizeof(unsigned long long), stream));
     if (stats) {
-        HIP_TRY(hipMemsetAsync(scene->counter.p, 0, sizeof(unsigned long long), stream));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    dim3 grid((pr->nx + 15) / 16, (pr->ny + 15) / 16), block(kBlock);
+    const uint32_t n_tiles = ((pr->nx + 7) / 8) * ((pr->ny + 7) / 8);
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + kRenderWaves - 1) / kRenderWaves);
+    dim3 grid(blocks), block(kRenderBlock);
     DCamera cam = to_dcamera(camera);
-    unsigned long long *counter = stats ? scene->counter.p : nullptr;
-    if (pr->accum_type == RT_ACCUM_F32)
-        hipLaunchKernelGGL(k_render<float>, grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
-                           pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (float *)accum_dev, counter);
-    else
-        hipLaunchKernelGGL(k_render<double>, grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,
-                           pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (double *)accum_dev, counter);
+    if (scene->render_lds_bytes > kLdsBudget) return fail(RT_E_UNSUPPORTED, "rt_render: traversal stacks need %zu bytes of LDS", scene->render_lds_bytes);
+    const bool lds_tree = scene->render_lds_tree_bytes <= kLdsBudget;
+    const size_t lds = lds_tree ? scene->render_lds_tree_bytes : scene->render_lds_bytes;
+#define RT_LAUNCH(T, L)                                                                                                  \
+    hipLaunchKernelGGL((k_render<T, L>), grid, block, lds, stream, scene->d, cam, pr->nx, pr->ny, pr->sample_begin,         \
+                       pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (T *)accum_dev, scene->counter.p,               \
+                       scene->n_nodes_dev, scene->n_prims_dev)
+    if (pr->accum_type == RT_ACCUM_F32) { if (lds_tree) RT_LAUNCH(float, true); else RT_LAUNCH(float, false); }
+    else { if (lds_tree) RT_LAUNCH(double, true); else RT_LAUNCH(double, false); }
+#undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(ev1, stream));
