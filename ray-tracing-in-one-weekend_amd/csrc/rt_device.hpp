@@ -499,17 +499,23 @@ __device__ __forceinline__ v3 reflect(v3 v, v3 n) { return vsub(v, vmul(n, 2 * v
 template <class R>
 __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ray &r, v3 p, v3 n, R &g, v3 &att, Ray &out) {
     const DMat *m = sc.mats + mat;
+    const uint32_t kind = m->kind;
     out.o = p;
     out.time = r.time;
-    if (m->kind == RT_MAT_LAMBERTIAN) {
-        v3 target = vadd(vadd(p, n), random_in_unit_sphere(g));
+    // Lambertian and metal both start by drawing a point in the unit sphere
+    // (material.cpp:48,61) and draw nothing else: one rejection loop serves the lanes of
+    // both kinds instead of one loop per kind.
+    v3 rnd = mk(0, 0, 0);
+    if (kind != RT_MAT_DIELECTRIC) rnd = random_in_unit_sphere(g);
+    if (kind == RT_MAT_LAMBERTIAN) {
+        v3 target = vadd(vadd(p, n), rnd);
         att = texture_value(sc, m->tex, p);
         out.d = vsub(target, p);
         return true;
     }
-    if (m->kind == RT_MAT_METAL) {
+    if (kind == RT_MAT_METAL) {
         v3 reflected = reflect(vunit(r.d), n);
-        out.d = vadd(reflected, vmul(random_in_unit_sphere(g), m->fuzz));
+        out.d = vadd(reflected, vmul(rnd, m->fuzz));
         att = ld3(m->albedo);
         return vdot(out.d, n) > 0;
     }
@@ -531,7 +537,10 @@ __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ra
         refracted = vsub(vmul(vsub(uv, vmul(outward, dt)), ni_over_nt), vmul(outward, sqrt(disc)));
         double r0 = (1 - ri) / (1 + ri);
         double r1 = r0 * r0;
-        reflect_prob = r1 + (1 - r1) * pow(1 - cosine, 5.0);
+        // schlick (material.cpp:26-30).  pow(x, 5) is taken by repeated multiplication: at most
+        // 2 ulp from a correctly rounded pow, and the value is only compared with a uniform.
+        const double x = 1 - cosine, x2 = x * x;
+        reflect_prob = r1 + (1 - r1) * (x2 * x2 * x);
     }
     att = mk(1, 1, 1);
     out.d = uniform(g, 0.0, 1.0) < reflect_prob ? reflected : refracted;
@@ -558,8 +567,8 @@ template <class R> __device__ __forceinline__ Ray camera_ray(const DCamera &c, d
 
 // main.cpp:45-48
 __device__ __forceinline__ v3 sky(v3 d) {
-    v3 unit = vunit(d);
-    double t = 0.5 * (unit.y + 1.0);
+    const double unit_y = d.y / vlen(d);   // only the y component of the unit vector is used
+    double t = 0.5 * (unit_y + 1.0);
     return mk((1.0 - t) * 1.0 + t * 0.5, (1.0 - t) * 1.0 + t * 0.7, (1.0 - t) * 1.0 + t * 1.0);
 }
 
