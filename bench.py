@@ -75,6 +75,13 @@ def cpu_baseline(scene_path, cam15, nx, ny):
             "sample": f"{nx}x{ny} at 1 spp ({dt:.1f} s), C restatement of the reference (oracle/rt_oracle.c)"}
 
 
+def sample_range(rank, spp):
+    """Global sample indices [begin, end) that rank `rank` renders of every pixel: disjoint
+    across ranks, and -- the streams being keyed by (pixel, global sample) -- together the same
+    set of paths a single GPU would trace for world*spp samples."""
+    return rank * spp, (rank + 1) * spp
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +114,8 @@ def main():
 
     accum = torch.zeros(args.ny, args.nx, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    params = w.params(args.nx, args.ny, rank * args.spp, (rank + 1) * args.spp, seed=1, accum=rt.RT_ACCUM_F32)
+    s_begin, s_end = sample_range(rank, args.spp)
+    params = w.params(args.nx, args.ny, s_begin, s_end, seed=1, accum=rt.RT_ACCUM_F32)
     kernel_ms = []
 
     def step(record):

@@ -1,0 +1,53 @@
+"""The N>1 protocol on CPU: world size 2 over gloo.  Each rank renders its sample range of
+every pixel (here with the oracle standing in for the GPU kernel, which renders the same
+per-(pixel, sample) streams), the float sums are all-reduced as bench.py does over RCCL,
+and the result must equal a single rank rendering all the samples."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, recipe
+
+
+def _worker(rank, world, port, spp, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import oracle_lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cam15 = np.load(os.path.join(ROOT, "tests", "golden", "frames.npz"))["camera"]
+    s0, s1 = bench.sample_range(rank, spp)
+    sums, _ = oracle_lib.Scene(os.path.join(ROOT, "tests", "golden", "scenes", "mixed.recipe")).render(
+        cam15, 32, 16, s0, s1, 99, oracle_lib.ORC_RNG_STREAM)
+    accum = torch.from_numpy(sums.astype(np.float32))
+    dist.all_reduce(accum)
+    if rank == 0:
+        np.save(out_path, accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_ranges_partition():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 4, 8):
+        r = [bench.sample_range(k, 1024) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == world * 1024
+        assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+
+
+def test_two_ranks_sum_to_one_rank(orc, tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sum.npy")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, 3, out), nprocs=2, join=True)
+    got = np.load(out)
+    whole, _ = orc.Scene(recipe("mixed")).render(golden("frames")["camera"], 32, 16, 0, 6, 99, orc.ORC_RNG_STREAM)
+    np.testing.assert_allclose(got, whole.astype(np.float32), rtol=2e-6, atol=1e-6)
+    assert got.max() > 0
