@@ -36,6 +36,14 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
 FP64_PEAK_TFLOPS = 78.6      # MI355X vector FP64
 
 
+WORKLOADS = {
+    "book1": "book-1 random spheres, ~485 static spheres, lambertian/metal/dielectric (BASELINE configs[1])",
+    "book2": "book-2 scene: moving spheres + BVH + chequer ground, main.cpp:61-99 as written (BASELINE configs[2])",
+    "two_perlin": "two Perlin spheres through object_list, main.cpp:52-59 (the reference's default scene)",
+    "stress": "synthetic sphere field, one bvh over everything (BASELINE configs[4])",
+}
+
+
 def book_camera(aspect):
     # main.cpp:114-120
     return [13.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 20.0, aspect, 0.0, 10.0, 0.0, 1.0]
@@ -92,6 +100,7 @@ def main():
     ap.add_argument("--ny", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--camera", default="book", help="book (main.cpp:114-120) or 'fx,fy,fz,ax,ay,az,vfov'")
     args = ap.parse_args()
 
     import torch
@@ -107,9 +116,20 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
-    scene_path = args.scene if os.path.exists(args.scene) else os.path.join(SCENES, args.scene + ".recipe")
+    if args.scene.startswith("stress:"):          # e.g. stress:1000000 -- generated on the fly (configs[4])
+        import tempfile
+        scene_path = os.path.join(tempfile.gettempdir(), f"rtiow_{args.scene.replace(':', '_')}_{os.getpid()}.recipe")
+        rt.generate("stress", 1, scene_path, n=int(args.scene.split(":")[1]))
+    else:
+        scene_path = args.scene if os.path.exists(args.scene) else os.path.join(SCENES, args.scene + ".recipe")
     cam15 = book_camera(args.nx / args.ny)
+    if args.camera != "book":
+        v = [float(x) for x in args.camera.split(",")]
+        cam15[0:6] = v[0:6]
+        cam15[9] = v[6]
+    t_build = time.perf_counter()
     w = rt.World(scene_path, device=local_rank)
+    t_build = time.perf_counter() - t_build
     cam = rt.camera(cam15)
 
     accum = torch.zeros(args.ny, args.nx, 3, dtype=torch.float32, device="cuda")
@@ -165,10 +185,10 @@ def main():
             "metric": "Mpaths/s at 1080p random-spheres", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.scene}: book-1 random spheres ({args.nx}x{args.ny}, {args.spp} spp per GPU per step, "
-                                   "max depth 50, BVH built by the reference algorithm)",
+            "config": {"workload": f"{WORKLOADS.get(args.scene.split(':')[0], args.scene)} [{args.scene}] ({args.nx}x{args.ny}, "
+                                   f"{args.spp} spp per GPU per step, max depth 50, BVH built by the reference algorithm)",
                        "nx": args.nx, "ny": args.ny, "spp_per_gpu": args.spp, "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
-            "rays_per_path": last.rays / last.paths, "mean_radiance": mean,
+            "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_render<float>", "kernel_ms": k_s * 1e3,
                          "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,

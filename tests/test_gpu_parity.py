@@ -254,3 +254,32 @@ def test_resolve(rt):
     torch.cuda.synchronize()
     exp = (255.99 * np.sqrt(sums.cpu().numpy().astype(np.float64) / 8)).astype(int)
     assert np.array_equal(out.cpu().numpy().astype(int), exp)
+
+
+def test_million_sphere_tree(rt, orc, tmp_path):
+    # BASELINE configs[4]: 10^6 spheres -> 1 048 575 reference nodes, 20 levels; the tree does not
+    # fit LDS, so this exercises the device-memory walk.  Hits are compared with the oracle.
+    path = str(tmp_path / "stress1m.recipe")
+    rt.generate("stress", 1, path, n=1000000)
+    w = rt.World(path)
+    nodes, _ = w.tables()
+    assert len(nodes) == 1048575
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = np.column_stack([rng.uniform(-500, 500, n), rng.uniform(0.5, 40, n), rng.uniform(-500, 500, n)])
+    tgt = np.column_stack([rng.uniform(-500, 500, n), rng.uniform(-2, 1, n), rng.uniform(-500, 500, n)])
+    rays = np.hstack([o, tgt - o, rng.uniform(-1, 1, (n, 1))])
+    h = w.trace(rays, 0.001, np.finfo(np.float64).max)
+    hit, prim, tpn = orc.Scene(path).trace(rays, 0.001, np.finfo(np.float64).max)
+    assert np.array_equal(h["hit"], hit.astype(np.int32))
+    assert np.array_equal(h["prim"], prim)
+    m = hit == 1
+    assert np.array_equal(h["t"][m], tpn[m, 0]) and np.array_equal(h["normal"][m], tpn[m, 4:7])
+    assert m.mean() > 0.9
+    # a small frame through the device-memory variant of the render kernel, against the oracle
+    cam15 = [0.0, 25.0, 60.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 40.0, 2.0, 0.0, 10.0, 0.0, 1.0]
+    got, stats = w.render(rt.camera(cam15), 48, 24, 0, 2, 5, rt.RT_ACCUM_F64)
+    exp, counters = orc.Scene(path).render(cam15, 48, 24, 0, 2, 5, orc.ORC_RNG_STREAM)
+    assert stats.rays == counters.rays
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+    w.close()
