@@ -181,6 +181,12 @@ def main():
         k_s = float(np.mean(kernel_ms)) / 1e3
         launch_paths = args.nx * args.ny * args.spp
         achieved = launch_paths * bytes_per_path / k_s / 1e9
+        # HBM bytes of one k_render launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE
+        # doubled for gfx950 + WRITE_SIZE); only valid for the configuration it was collected on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and (args.scene, args.nx, args.ny, args.spp) == ("book1", 1920, 1080, 1024):
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         line = {
             "metric": "Mpaths/s at 1080p random-spheres", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -190,7 +196,8 @@ def main():
                        "nx": args.nx, "ny": args.ny, "spp_per_gpu": args.spp, "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
             "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_render<float>", "kernel_ms": k_s * 1e3,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
+                         "algorithmic_bytes_per_launch": launch_paths * bytes_per_path, "kernel": "k_render<float, lds_tree>", "kernel_ms": k_s * 1e3,
                          "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,
                          "valu_f64": {"achieved_tflops": launch_paths * flops_per_path / k_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                                       "frac": launch_paths * flops_per_path / k_s / 1e12 / FP64_PEAK_TFLOPS}},
