@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--ny", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--camera", default="book", help="book (main.cpp:114-120) or 'fx,fy,fz,ax,ay,az,vfov'")
     args = ap.parse_args()
 
@@ -111,9 +113,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
     if args.scene.startswith("stress:"):          # e.g. stress:1000000 -- generated on the fly (configs[4])

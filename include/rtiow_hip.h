@@ -138,7 +138,9 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
  * [sample_begin, sample_end) of every pixel into accum (DEVICE memory on the scene's
  * GPU, nx*ny*3 values of accum_type, row-major, top image row first), asynchronously
  * on `stream` (a hipStream_t, or NULL).  stats may be NULL; when given, the call
- * synchronises the stream and fills it. */
+ * synchronises the stream and fills it.  At most 2^24 samples per pixel per call.  A scene
+ * carries the frame's tile queue: renders of ONE scene must not overlap in time (use one
+ * scene per stream if they must). */
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 

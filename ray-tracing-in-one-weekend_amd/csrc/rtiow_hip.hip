@@ -670,6 +670,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     if (pr->nx == 0 || pr->ny == 0) return fail(RT_E_INVALID, "rt_render: empty image");
     if ((uint64_t)pr->nx * pr->ny > 0xFFFFFFFFull / 3) return fail(RT_E_INVALID, "rt_render: image too large");
     if (pr->sample_end < pr->sample_begin) return fail(RT_E_INVALID, "rt_render: sample_end < sample_begin");
+    if (pr->sample_end - pr->sample_begin > (1u << 24)) return fail(RT_E_INVALID, "rt_render: more than 2^24 samples per pixel in one call");
     if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render: unknown accum_type %u", pr->accum_type);
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
