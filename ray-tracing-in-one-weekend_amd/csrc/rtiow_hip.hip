@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -396,6 +397,145 @@ struct flattener {
         nodes[me] = out;
         return me;
     }
+
+    // ---- re-clustering ------------------------------------------------------------------
+    // Which leaves a ray reaches in the reference's tree depends only on the leaves' own
+    // boxes: a node's box is the exact union (fmin/fmax, aabb.cpp:59-64) of its children's,
+    // IEEE rounding is monotone, so whenever the slab test of a leaf's box passes, the test
+    // of every box that contains it passes too (aabb.cpp:8-57 with the same ray and
+    // interval).  "All ancestors' boxes hit" is therefore equivalent to "the leaf's box is
+    // hit", and ANY tree whose inner boxes are exact unions of the reference's leaf boxes
+    // reaches exactly the reference's leaves.  The reference's random-axis median split
+    // costs ~19 node visits per ray on the 485-sphere scene; a surface-area-heuristic tree
+    // over the same leaves costs ~12.  Primitives keep the reference's left-to-right
+    // numbering, which is what decides ties.
+    struct leaf_rec { int32_t ref; double box[6]; bool safe; };
+    std::vector<leaf_rec> leaves;
+
+    void collect(int32_t id, uint32_t depth) {
+        if (error) return;
+        if (depth > 64) { error = "bvh deeper than 64 levels (or cyclic)"; return; }
+        const rt_node_desc nd = desc->nodes[id];
+        const int32_t ref[2] = {nd.left, nd.right};
+        for (int c = 0; c < 2; ++c)
+            if (ref[c] >= 0 ? (uint32_t)ref[c] >= desc->n_nodes : (uint32_t)~ref[c] >= desc->n_prims) { error = "node child out of range"; return; }
+        leaf_rec lr;
+        for (int a = 0; a < 3; ++a) { lr.box[2 * a] = nd.box_min[a]; lr.box[2 * a + 1] = nd.box_max[a]; }
+        if (ref[0] < 0 && ref[1] < 0) {
+            lr.ref = leaf_of(~ref[0], ~ref[1], lr.safe);
+            leaves.push_back(lr);
+            return;
+        }
+        for (int c = 0; c < 2; ++c) {
+            if (ref[c] >= 0) collect(ref[c], depth + 1);
+            else {   // a primitive beside a subtree is tested whenever this node's box is hit
+                lr.ref = leaf_of(~ref[c], ~ref[c], lr.safe);
+                leaves.push_back(lr);
+            }
+            if (error) return;
+        }
+    }
+
+    static double half_area(const double *b) {
+        const double dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static void grow(double *b, const double *o) {
+        for (int a = 0; a < 3; ++a) { b[2 * a] = std::fmin(b[2 * a], o[2 * a]); b[2 * a + 1] = std::fmax(b[2 * a + 1], o[2 * a + 1]); }
+    }
+    static void empty_box(double *b) { for (int a = 0; a < 3; ++a) { b[2 * a] = HUGE_VAL; b[2 * a + 1] = -HUGE_VAL; } }
+
+    // binned surface-area heuristic over leaves[first, first+count); returns the split position
+    size_t split(size_t first, size_t count) {
+        constexpr int BINS = 32;
+        double cb[6];
+        empty_box(cb);
+        for (size_t i = first; i < first + count; ++i) {
+            const double *b = leaves[i].box;
+            for (int a = 0; a < 3; ++a) { const double c = 0.5 * (b[2 * a] + b[2 * a + 1]); cb[2 * a] = std::fmin(cb[2 * a], c); cb[2 * a + 1] = std::fmax(cb[2 * a + 1], c); }
+        }
+        double best_cost = HUGE_VAL;
+        int best_axis = -1, best_bin = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double lo = cb[2 * a], ext = cb[2 * a + 1] - lo;
+            if (!(ext > 0) || !std::isfinite(ext)) continue;
+            double bb[BINS][6];
+            size_t bn[BINS] = {0};
+            for (int k = 0; k < BINS; ++k) empty_box(bb[k]);
+            for (size_t i = first; i < first + count; ++i) {
+                const double *b = leaves[i].box;
+                int k = (int)((0.5 * (b[2 * a] + b[2 * a + 1]) - lo) / ext * BINS);
+                k = k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
+                grow(bb[k], b);
+                bn[k]++;
+            }
+            double ra[BINS];
+            size_t rn[BINS];
+            double acc[6];
+            empty_box(acc);
+            size_t n = 0;
+            for (int k = BINS - 1; k > 0; --k) { if (bn[k]) grow(acc, bb[k]); n += bn[k]; ra[k] = n ? half_area(acc) : 0; rn[k] = n; }
+            empty_box(acc);
+            n = 0;
+            for (int k = 0; k < BINS - 1; ++k) {
+                if (bn[k]) grow(acc, bb[k]);
+                n += bn[k];
+                if (n == 0 || rn[k + 1] == 0) continue;
+                const double cost = half_area(acc) * (double)n + ra[k + 1] * (double)rn[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+            }
+        }
+        if (best_axis < 0) return first + count / 2;   // coincident centres: any split will do
+        const int a = best_axis;
+        const double lo = cb[2 * a], ext = cb[2 * a + 1] - lo;
+        auto mid = std::partition(leaves.begin() + (long)first, leaves.begin() + (long)(first + count), [&](const leaf_rec &l) {
+            int k = (int)((0.5 * (l.box[2 * a] + l.box[2 * a + 1]) - lo) / ext * BINS);
+            k = k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
+            return k <= best_bin;
+        });
+        size_t pos = (size_t)(mid - leaves.begin());
+        if (pos == first || pos == first + count) pos = first + count / 2;
+        return pos;
+    }
+
+    // builds the node over leaves[first, first+count) (count >= 2); out_box receives its exact union box
+    int32_t cluster(size_t first, size_t count, uint32_t depth, double *out_box, bool &safe) {
+        if (depth + 1 > max_depth) max_depth = depth + 1;
+        // a tree this deep means the heuristic keeps peeling single leaves: fall back to halving
+        const size_t pos = depth > 48 ? first + count / 2 : split(first, count);
+        const int me = (int)nodes.size();
+        nodes.emplace_back();
+        DNode out;
+        memset(&out, 0, sizeof out);
+        bool safe_c[2];
+        const size_t beg[2] = {first, pos}, cnt[2] = {pos - first, first + count - pos};
+        for (int c = 0; c < 2; ++c) {
+            if (cnt[c] == 1) {
+                out.child[c] = leaves[beg[c]].ref;
+                memcpy(out.bx[c], leaves[beg[c]].box, sizeof out.bx[c]);
+                safe_c[c] = leaves[beg[c]].safe;
+            } else {
+                out.child[c] = cluster(beg[c], cnt[c], depth + 1, out.bx[c], safe_c[c]);
+            }
+        }
+        if (safe_c[0]) out.flags |= NF_SAFE0;
+        if (safe_c[1]) out.flags |= NF_SAFE1;
+        safe = safe_c[0] && safe_c[1];
+        memcpy(out_box, out.bx[0], sizeof out.bx[0]);
+        grow(out_box, out.bx[1]);
+        nodes[me] = out;
+        return me;
+    }
+
+    // the whole bvh item rooted at description node `id`, re-clustered
+    int32_t build_clustered(int32_t id, bool &safe) {
+        leaves.clear();
+        collect(id, 0);
+        if (error) return REF_NONE;
+        if (leaves.size() == 1) { safe = leaves[0].safe; return leaves[0].ref; }
+        double box[6];
+        return cluster(0, leaves.size(), 0, box, safe);
+    }
 };
 
 int check_desc(const rt_scene_desc *d) {
@@ -451,6 +591,10 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (device < 0 || device >= ndev) return fail(RT_E_INVALID, "device %d out of range (have %d)", device, ndev);
 
     flattener fl;
+    // RTIOW_TREE=reference keeps the reference's own topology on the device (for A/B and for the
+    // test that both layouts give bit-identical results); the default re-clusters its leaves.
+    const char *tree_env = getenv("RTIOW_TREE");
+    const bool reference_layout = tree_env && strcmp(tree_env, "reference") == 0;
     fl.desc = desc;
     std::vector<DItem> items;
     for (uint32_t i = 0; i < desc->n_items; ++i) {
@@ -462,7 +606,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             const rt_node_desc &root = desc->nodes[it.index];
             for (int a = 0; a < 3; ++a) { di.box[2 * a] = root.box_min[a]; di.box[2 * a + 1] = root.box_max[a]; }
             di.has_box = 1;
-            di.ref = fl.build(it.index, 0, safe);
+            di.ref = reference_layout ? fl.build(it.index, 0, safe) : fl.build_clustered(it.index, safe);
         } else {
             di.ref = fl.leaf_of(it.index, it.index, safe);
         }
@@ -536,6 +680,10 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     }
+    if (getenv("RTIOW_VERBOSE"))
+        fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render LDS %zu B without / %zu B with the tree (budget %zu)\n",
+                fl.nodes.size(), fl.prims.size(), fl.max_depth, reference_layout ? "reference" : "re-clustered",
+                s->render_lds_bytes, s->render_lds_tree_bytes, kLdsBudget);
     *out = s;
     return RT_OK;
 }

@@ -283,3 +283,26 @@ def test_million_sphere_tree(rt, orc, tmp_path):
     assert stats.rays == counters.rays
     np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
     w.close()
+
+
+@pytest.mark.parametrize("scene", ["book1", "book2", "stress4096", "mixed", "ties"])
+def test_reclustered_tree_equals_reference_layout(rt, scene, monkeypatch):
+    # The device tree is re-clustered over the reference's leaves (surface-area heuristic); with
+    # RTIOW_TREE=reference the reference's own topology is uploaded instead.  Both must give the
+    # same hits to the bit, and the same frames: which leaves a ray reaches depends only on the
+    # leaves' boxes.
+    g = golden("trace_" + scene)
+    monkeypatch.setenv("RTIOW_TREE", "reference")
+    w_ref = rt.World(recipe(scene))
+    monkeypatch.delenv("RTIOW_TREE")
+    w_new = rt.World(recipe(scene))
+    a = w_ref.trace(g["rays"], float(g["tmin"]), float(g["tmax"]))
+    b = w_new.trace(g["rays"], float(g["tmin"]), float(g["tmax"]))
+    assert a.tobytes() == b.tobytes()
+    cam = rt.camera(g_cam := golden("frames")["camera"])
+    fa, sa = w_ref.render(cam, 64, 32, 0, 6, 4)
+    fb, sb = w_new.render(cam, 64, 32, 0, 6, 4)
+    assert sa.rays == sb.rays
+    np.testing.assert_allclose(fa, fb, rtol=1e-13, atol=1e-13)
+    w_ref.close()
+    w_new.close()
