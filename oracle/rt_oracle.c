@@ -626,8 +626,11 @@ void orc_camera_init(ocamera *c, ovec3 from, ovec3 at, ovec3 up, double vfov, do
 /* camera.cpp:16-21,38-48: the lens disk is sampled even when the radius is zero, and
  * the shutter time reuses the {-1,1} distribution */
 oray orc_camera_get_ray(const ocamera *c, double s, double t, orng *g) {
-    ovec3 p;
-    for (;;) {
+    ovec3 p = {0, 0, 0};
+    /* The GPU's per-path streams skip the lens sample when the radius is zero (its value is
+     * multiplied by the radius); the shared-mt19937 and tape modes draw it as the reference does. */
+    const int skip = g->kind == ORC_RNG_STREAM && c->lens_radius == 0;
+    while (!skip) {
         p.x = orc_uniform(g, -1, 1);
         p.y = orc_uniform(g, -1, 1);
         p.z = 0;

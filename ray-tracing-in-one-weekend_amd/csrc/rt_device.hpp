@@ -148,6 +148,9 @@ struct StreamRng {
         return (double)(((hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
     }
     __device__ __forceinline__ bool exhausted() const { return false; }
+    // a stream owes nobody a particular draw count: draws whose values cannot reach the
+    // result may be skipped (see camera_ray)
+    static constexpr bool kMaySkipDeadDraws = true;
 };
 
 // uniforms handed in by the caller, consumed in order
@@ -162,6 +165,8 @@ struct TapeRng {
         return u;
     }
     __device__ __forceinline__ bool exhausted() const { return over; }
+    // a tape replays the reference's draws one for one
+    static constexpr bool kMaySkipDeadDraws = false;
 };
 
 // std::uniform_real_distribution<double>{a, b}
@@ -550,11 +555,17 @@ __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ra
 // ---------------------------------------------------------------------- camera ----
 // camera.cpp:16-21,38-48
 template <class R> __device__ __forceinline__ Ray camera_ray(const DCamera &c, double s, double t, R &g) {
-    double px, py;
-    do {
-        px = uniform(g, -1.0, 1.0);
-        py = uniform(g, -1.0, 1.0);
-    } while (!(px * px + py * py + 0.0 * 0.0 < 1) && !g.exhausted());
+    // The reference samples the lens disk even when the lens radius is zero (camera.cpp:39),
+    // which only matters for the position of later draws in its one shared generator.  The
+    // sample is multiplied by the radius, so with a zero radius a per-path stream skips
+    // the rejection loop; the tape variant, which replays the reference's draws, keeps it.
+    double px = 0, py = 0;
+    if (!(R::kMaySkipDeadDraws && c.lens_radius == 0)) {
+        do {
+            px = uniform(g, -1.0, 1.0);
+            py = uniform(g, -1.0, 1.0);
+        } while (!(px * px + py * py + 0.0 * 0.0 < 1) && !g.exhausted());
+    }
     v3 rd = vmul(mk(px, py, 0), c.lens_radius);
     v3 offset = vadd(vmul(ld3(c.u), rd.x), vmul(ld3(c.v), rd.y));
     double time = c.t0 + uniform(g, -1.0, 1.0) * (c.t1 - c.t0);
