@@ -62,17 +62,37 @@ def algorithmic_counts(scene_path, cam15):
             "sphere_tests_per_ray": c.sphere_tests / c.rays, "moving_tests_per_ray": c.moving_tests / c.rays}
 
 
+def _ref_render(binary, scene_path, cam15, nx, ny, spp, seed):
+    return subprocess.Popen([binary, "render", scene_path, str(seed), str(nx), str(ny), str(spp), *map(repr, cam15), "-"],
+                            stdout=subprocess.PIPE, text=True)
+
+
 def cpu_baseline(scene_path, cam15, nx, ny):
-    """The reference renderer on one host core over a bounded sample of the same frame."""
+    """The reference renderer on the host over a bounded sample of the same frame: one core
+    with the reference's own flags (the headline `value`), one core without the debug-mode
+    standard library, and one process per available core, each rendering the frame with its
+    own seed (the parallelisation the reference's README suggests)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_capture")
     spp = 2
     if os.path.exists(ref):
-        out = subprocess.run([ref, "render", scene_path, "1", str(nx), str(ny), str(spp), *map(repr, cam15), "-"],
-                             check=True, capture_output=True, text=True).stdout
-        r = json.loads(out)
-        return {"value": r["mpaths_per_s"], "unit": "Mpaths/s", "cores": 1, "kind": "reference",
-                "sample": f"{nx}x{ny} at {spp} spp ({nx * ny * spp / 1e6:.2f} M paths, {r['render_seconds']:.1f} s), "
-                          "reference classes built with the reference's flags (-O3 -D_GLIBCXX_DEBUG -DNDEBUG), single thread as shipped"}
+        r = json.loads(_ref_render(ref, scene_path, cam15, nx, ny, spp, 1).communicate()[0])
+        out = {"value": r["mpaths_per_s"], "unit": "Mpaths/s", "cores": 1, "kind": "reference",
+               "sample": f"{nx}x{ny} at {spp} spp ({nx * ny * spp / 1e6:.2f} M paths, {r['render_seconds']:.1f} s), "
+                         "reference classes built with the reference's flags (-O3 -D_GLIBCXX_DEBUG -DNDEBUG), single thread as shipped"}
+        fast = ref + "_nodebug"
+        if os.path.exists(fast):
+            r = json.loads(_ref_render(fast, scene_path, cam15, nx, ny, spp, 1).communicate()[0])
+            out["without_debug_stdlib"] = {"value": r["mpaths_per_s"], "cores": 1, "sample": f"same frame, -O3 -DNDEBUG, {r['render_seconds']:.1f} s"}
+            cores = min(16, len(os.sched_getaffinity(0)))
+            t0 = time.perf_counter()
+            procs = [_ref_render(fast, scene_path, cam15, nx, ny, 1, 100 + k) for k in range(cores)]
+            outs = [pr.communicate()[0] for pr in procs]
+            dt = time.perf_counter() - t0
+            if all(pr.returncode == 0 for pr in procs):
+                out["all_cores"] = {"value": sum(json.loads(o)["mpaths_per_s"] for o in outs), "cores": cores,
+                                    "sample": f"{cores} concurrent processes x ({nx}x{ny} at 1 spp, own seed), -O3 -DNDEBUG, "
+                                              f"sum of their rates, wall {dt:.1f} s"}
+        return out
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     s = oracle_lib.Scene(scene_path)
@@ -81,6 +101,23 @@ def cpu_baseline(scene_path, cam15, nx, ny):
     dt = time.perf_counter() - t0
     return {"value": nx * ny / dt / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
             "sample": f"{nx}x{ny} at 1 spp ({dt:.1f} s), C restatement of the reference (oracle/rt_oracle.c)"}
+
+
+def image_check(rt, world, scene):
+    """RMSE of a 120x60, 256-spp GPU frame against a frame the reference rendered at the same
+    size and sample count (tests/golden/frames.npz), beside the RMSE between two reference
+    seeds: two independent estimates of the same image differ by about that much."""
+    path = os.path.join(ROOT, "tests", "golden", "frames.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if scene + "_spp256_seed1" not in g.files:
+        return None
+    a, b = g[scene + "_spp256_seed1"].astype(np.float64), g[scene + "_spp256_seed2"].astype(np.float64)
+    sums, _ = world.render(rt.camera(g["camera"]), 120, 60, 0, 256, 77)
+    img = sums / 256
+    return {"rmse_vs_reference": float(np.sqrt(np.mean((img - a) ** 2))), "rmse_between_reference_seeds": float(np.sqrt(np.mean((a - b) ** 2))),
+            "frame": "120x60, 256 spp, linear radiance"}
 
 
 def sample_range(rank, spp):
@@ -211,6 +248,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene_path, cam15, args.nx, args.ny)
+        if world == 1:
+            line["image_check"] = image_check(rt, w, args.scene)
         print(json.dumps(line), flush=True)
     w.close()
     if world > 1:

@@ -820,6 +820,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     if (pr->sample_end < pr->sample_begin) return fail(RT_E_INVALID, "rt_render: sample_end < sample_begin");
     if (pr->sample_end - pr->sample_begin > (1u << 24)) return fail(RT_E_INVALID, "rt_render: more than 2^24 samples per pixel in one call");
     if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render: unknown accum_type %u", pr->accum_type);
+    if (scene->render_lds_bytes > kLdsBudget) return fail(RT_E_UNSUPPORTED, "rt_render: traversal stacks need %zu bytes of LDS", scene->render_lds_bytes);
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -834,7 +835,6 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + kRenderWaves - 1) / kRenderWaves);
     dim3 grid(blocks), block(kRenderBlock);
     DCamera cam = to_dcamera(camera);
-    if (scene->render_lds_bytes > kLdsBudget) return fail(RT_E_UNSUPPORTED, "rt_render: traversal stacks need %zu bytes of LDS", scene->render_lds_bytes);
     const bool lds_tree = scene->render_lds_tree_bytes <= kLdsBudget;
     const size_t lds = lds_tree ? scene->render_lds_tree_bytes : scene->render_lds_bytes;
 #define RT_LAUNCH(T, L)                                                                                                  \
