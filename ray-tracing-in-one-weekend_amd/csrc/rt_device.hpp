@@ -142,11 +142,20 @@ struct StreamRng {
         s3 = (s3 << 11) | (s3 >> 21);
         return result;
     }
-    __device__ __forceinline__ double canonical() {
-        uint64_t hi = next();
-        uint64_t lo = next();
-        return (double)(((hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+    // The draw is k * 2^-53 with k = (hi:lo) >> 11, a 53-bit integer.  It is formed without an
+    // integer-to-double conversion: the low 52 bits of k are the fraction of a double x in
+    // [1, 2), and with top = bit 52 of k, k * 2^-53 = (x - 1 + top) / 2.  Every step is exact.
+    __device__ __forceinline__ double twice_canonical() {
+        const uint32_t hi = next();
+        const uint32_t lo = next();
+        const uint32_t xlo = __builtin_amdgcn_alignbit(hi, lo, 11);
+        const uint32_t xhi = 0x3FF00000u | ((hi >> 11) & 0xFFFFFu);
+        const double x = __hiloint2double((int)xhi, (int)xlo);
+        return x + ((hi >> 31) ? 0.0 : -1.0);
     }
+    __device__ __forceinline__ double canonical() { return twice_canonical() * 0.5; }
+    // uniform_real_distribution{-1, 1}: canonical * 2 + -1, where canonical * 2 is exact
+    __device__ __forceinline__ double symmetric() { return twice_canonical() + -1.0; }
     __device__ __forceinline__ bool exhausted() const { return false; }
     // a stream owes nobody a particular draw count: draws whose values cannot reach the
     // result may be skipped (see camera_ray)
@@ -164,15 +173,11 @@ struct TapeRng {
         ++pos;
         return u;
     }
+    __device__ __forceinline__ double symmetric() { return (canonical() * (1.0 - -1.0)) + -1.0; }
     __device__ __forceinline__ bool exhausted() const { return over; }
     // a tape replays the reference's draws one for one
     static constexpr bool kMaySkipDeadDraws = false;
 };
-
-// std::uniform_real_distribution<double>{a, b}
-template <class R> __device__ __forceinline__ double uniform(R &g, double a, double b) {
-    return (g.canonical() * (b - a)) + a;
-}
 
 // ------------------------------------------------------------------- box test ----
 // aabb::hit (aabb.cpp:8-57).  b = min x, max x, min y, max y, min z, max z.  The bounds
@@ -490,9 +495,9 @@ __device__ __forceinline__ v3 texture_value(const DScene &sc, uint32_t tex, v3 p
 template <class R> __device__ __forceinline__ v3 random_in_unit_sphere(R &g) {
     v3 c;
     do {
-        c.x = uniform(g, -1.0, 1.0);
-        c.y = uniform(g, -1.0, 1.0);
-        c.z = uniform(g, -1.0, 1.0);
+        c.x = g.symmetric();   // dist{-1, 1} (material.cpp:42)
+        c.y = g.symmetric();
+        c.z = g.symmetric();
     } while (!(c.x * c.x + c.y * c.y + c.z * c.z < 1) && !g.exhausted());
     return c;
 }
@@ -548,7 +553,7 @@ __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ra
         reflect_prob = r1 + (1 - r1) * (x2 * x2 * x);
     }
     att = mk(1, 1, 1);
-    out.d = uniform(g, 0.0, 1.0) < reflect_prob ? reflected : refracted;
+    out.d = g.canonical() < reflect_prob ? reflected : refracted;   // dist{0, 1}: u * 1 + 0 = u
     return true;
 }
 
@@ -562,13 +567,13 @@ template <class R> __device__ __forceinline__ Ray camera_ray(const DCamera &c, d
     double px = 0, py = 0;
     if (!(R::kMaySkipDeadDraws && c.lens_radius == 0)) {
         do {
-            px = uniform(g, -1.0, 1.0);
-            py = uniform(g, -1.0, 1.0);
+            px = g.symmetric();   // camera.cpp:19 draws from dist{-1, 1}
+            py = g.symmetric();
         } while (!(px * px + py * py + 0.0 * 0.0 < 1) && !g.exhausted());
     }
     v3 rd = vmul(mk(px, py, 0), c.lens_radius);
     v3 offset = vadd(vmul(ld3(c.u), rd.x), vmul(ld3(c.v), rd.y));
-    double time = c.t0 + uniform(g, -1.0, 1.0) * (c.t1 - c.t0);
+    double time = c.t0 + g.symmetric() * (c.t1 - c.t0);
     Ray r;
     r.o = vadd(ld3(c.origin), offset);
     r.d = vsub(vsub(vadd(vadd(ld3(c.llc), vmul(ld3(c.horizontal), s)), vmul(ld3(c.vertical), t)), ld3(c.origin)), offset);

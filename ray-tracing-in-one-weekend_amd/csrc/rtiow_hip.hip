@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kRenderBlock) void k_render(DScene sc, DCamera cam,
                         const uint32_t smp = s_begin + (k >> 6);
                         g.init(seed, y * nx + x, smp);
                         // the reference's row index runs bottom-up (main.cpp:126)
-                        const double ii = (double)x + uniform(g, 0.0, 1.0);
-                        const double jj = (double)(ny - 1 - y) + uniform(g, 0.0, 1.0);
+                        const double ii = (double)x + g.canonical();   // dist{0, 1}: u * 1 + 0 = u
+                        const double jj = (double)(ny - 1 - y) + g.canonical();
                         const double u = ii / (double)nx, v = jj / (double)ny;
                         r = camera_ray(cam, u, v, g);
                         thr = mk(1, 1, 1);
