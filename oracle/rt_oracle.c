@@ -655,13 +655,16 @@ static void camera_from_array(ocamera *c, const double *a) {
 /* ------------------------------------------------------------- integrator --- */
 /* main.cpp:30-50: scatter is evaluated before the depth test; the product with the
  * attenuation is taken on the way back up the recursion. */
+static int g_max_depth = 50;   /* the constant of main.cpp:34 */
+void orc_set_max_depth(int depth) { g_max_depth = depth; }
+
 void orc_ray_colour(const oscene *s, const oray *r, int depth, orng *g, double out[3]) {
     ohit h;
     if (orc_world_hit(s, r, 0.001, DBL_MAX, &h)) {
         double att[3];
         oray sc;
         int scattered = orc_scatter(s, s->prim[h.prim].mat, r, &h, g, att, &sc);
-        if (depth < 50 && scattered) {
+        if (depth < g_max_depth && scattered) {
             double next[3];
             orc_ray_colour(s, &sc, depth + 1, g, next);
             out[0] = next[0] * att[0]; out[1] = next[1] * att[1]; out[2] = next[2] * att[2];

@@ -128,6 +128,9 @@ void orc_scatter_batch(const oscene *s, const int32_t *prim, const double *rays 
                        uint8_t *scattered, double *att /*[n][3]*/, double *out_rays /*[n][7]*/, int32_t *used);
 void orc_camera_batch(const double *cam /*[10]: from at up? see .c*/, const double *st /*[n][2]*/,
                       const double *tape, int k, size_t n, double *out_rays /*[n][7]*/, int32_t *used);
+/* The bounce limit of main.cpp:34 (50 there); settable so that tests can compare renders at
+ * other limits.  Process-wide. */
+void orc_set_max_depth(int depth);
 /* render samples [s_begin, s_end) of every pixel.
  * mode ORC_RNG_MT: one shared mt19937(seed), draw order of main.cpp:126-141 (s_begin must be 0).
  * mode ORC_RNG_STREAM: per-(pixel, sample) streams, pixel = row-major index with the top row first.

@@ -45,6 +45,7 @@ def lib():
         L.orc_scatter_batch.argtypes = [vp, vp, vp, vp, vp, i32, sz, vp, vp, vp, vp]
         L.orc_camera_batch.argtypes = [vp, vp, vp, i32, sz, vp, vp]
         L.orc_render.argtypes = [vp, vp, i32, i32, i32, i32, ctypes.c_uint64, i32, vp]
+        L.orc_set_max_depth.argtypes = [i32]
         L.orc_counters_get.argtypes = [ctypes.POINTER(Counters)]
         L.orc_perlin_tables.argtypes = [vp, vp, vp, vp]
         L.orc_mt_seed.argtypes = [vp, ctypes.c_uint32]
@@ -142,12 +143,16 @@ class Scene:
         lib().orc_scatter_batch(self.h, _ptr(prim), _ptr(rays), _ptr(hits), _ptr(tape), tape.shape[1], n, _ptr(sc), _ptr(att), _ptr(out), _ptr(used))
         return sc, att, out, used
 
-    def render(self, cam15, nx, ny, s_begin, s_end, seed, mode):
+    def render(self, cam15, nx, ny, s_begin, s_end, seed, mode, max_depth=50):
         """Per-pixel sums over the samples, (ny, nx, 3), top row first; also the work counters."""
         cam = np.ascontiguousarray(cam15, dtype=np.float64)
         out = np.zeros((ny, nx, 3), np.float64)
         lib().orc_counters_reset()
-        lib().orc_render(self.h, _ptr(cam), nx, ny, s_begin, s_end, seed, mode, _ptr(out))
+        lib().orc_set_max_depth(max_depth)
+        try:
+            lib().orc_render(self.h, _ptr(cam), nx, ny, s_begin, s_end, seed, mode, _ptr(out))
+        finally:
+            lib().orc_set_max_depth(50)
         c = Counters()
         lib().orc_counters_get(ctypes.byref(c))
         return out, c

@@ -306,3 +306,45 @@ def test_reclustered_tree_equals_reference_layout(rt, scene, monkeypatch):
     np.testing.assert_allclose(fa, fb, rtol=1e-13, atol=1e-13)
     w_ref.close()
     w_new.close()
+
+
+EDGE_FRAMES = [
+    # nx, ny, first sample, one past the last, max depth, aperture
+    (1, 1, 0, 3, 50, 0.0),        # a single pixel: one ragged tile
+    (9, 3, 4, 5, 50, 0.0),        # one sample that is not sample 0
+    (16, 8, 0, 0, 50, 0.0),       # an empty sample range adds nothing
+    (24, 12, 0, 4, 0, 0.0),       # depth 0: scatter is still evaluated, then the path ends black (main.cpp:33-42)
+    (24, 12, 0, 4, 1, 0.0),
+    (40, 20, 0, 6, 50, 0.5),      # a real lens: the disk rejection loop runs (camera.cpp:16-21,39)
+]
+
+
+@pytest.mark.parametrize("nx,ny,s0,s1,depth,aperture", EDGE_FRAMES)
+def test_edge_frames_match_oracle(rt, orc, worlds, nx, ny, s0, s1, depth, aperture):
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = nx / ny
+    cam15[11] = aperture
+    got, stats = worlds("book2").render(rt.camera(cam15), nx, ny, s0, s1, 11, rt.RT_ACCUM_F64, max_depth=depth)
+    exp, counters = orc.Scene(recipe("book2")).render(cam15, nx, ny, s0, s1, 11, orc.ORC_RNG_STREAM, max_depth=depth)
+    assert stats.paths == nx * ny * (s1 - s0) == counters.paths
+    assert stats.rays == counters.rays
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+    if s1 == s0:
+        assert not got.any()
+
+
+def test_empty_world_is_all_sky(rt, orc, tmp_path):
+    # object_list::hit over no objects never hits (object_list.cpp:12-26): every path is one sky ray
+    path = tmp_path / "empty.recipe"
+    path.write_text("rtiow-recipe 1\n")
+    cam15 = np.array(golden("frames")["camera"])
+    w = rt.World(str(path))
+    try:
+        got, stats = w.render(rt.camera(cam15), 20, 10, 0, 2, 5, rt.RT_ACCUM_F64)
+        exp, counters = orc.Scene(str(path)).render(cam15, 20, 10, 0, 2, 5, orc.ORC_RNG_STREAM)
+        assert stats.rays == stats.paths == 400 == counters.rays
+        np.testing.assert_allclose(got, exp, rtol=1e-13)
+        rays = np.zeros((3, 7)); rays[:, 5] = 1.0
+        assert not w.trace(rays, 0.001, 1e30)["hit"].any()
+    finally:
+        w.close()
