@@ -256,16 +256,50 @@ struct Trav {
     int32_t bp;      // its primitive (device order), -1 = none
 };
 
-__device__ __forceinline__ int32_t trav_pop(Trav &tv, const int *stack, int stride) {
+// A lane's traversal stack.  Entry k lives in LDS at lds[k * stride] (the block's lanes are
+// interleaved) while k < cap; deeper entries, which only trees too large for LDS produce,
+// live in device memory at spill[(k - cap) * spill_stride].
+struct LaneStack {
+    int *lds;
+    int stride;
+    int cap;
+    int *spill;
+    int spill_stride;
+};
+
+template <bool SPILL> __device__ __forceinline__ void stack_put(const LaneStack &st, int k, int32_t v) {
+    if (!SPILL || k < st.cap) st.lds[k * st.stride] = v;
+    else st.spill[(size_t)(k - st.cap) * st.spill_stride] = v;
+}
+template <bool SPILL> __device__ __forceinline__ int32_t stack_get(const LaneStack &st, int k) {
+    if (!SPILL || k < st.cap) return st.lds[k * st.stride];
+    return st.spill[(size_t)(k - st.cap) * st.spill_stride];
+}
+
+template <bool SPILL> __device__ __forceinline__ int32_t trav_pop(Trav &tv, const LaneStack &st) {
     int32_t r = REF_NONE;
-    if (tv.sp > 0) { --tv.sp; r = stack[tv.sp * stride]; }
+    if (tv.sp > 0) { --tv.sp; r = stack_get<SPILL>(st, tv.sp); }
     return r;
 }
 
+template <bool SPILL>
+__device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, bool h1, double e0, double e1, const LaneStack &st, Trav &tv) {
+    const bool near0 = e0 <= e1;
+    if (h0 && h1) {
+        stack_put<SPILL>(st, tv.sp, near0 ? c1 : c0);
+        ++tv.sp;
+        tv.cur = near0 ? c0 : c1;
+    } else if (h0 || h1) {
+        tv.cur = h0 ? c0 : c1;
+    } else {
+        tv.cur = trav_pop<SPILL>(tv, st);
+    }
+}
+
 // One node: test both child boxes, continue with the nearer, push the farther.
-__device__ __forceinline__ void node_step(const DScene &sc, const RayCtx &r, double tmin, double tmax, int *stack,
-                                          int stride, Trav &tv) {
-    const DNode *nd = sc.nodes + tv.cur;
+template <bool SPILL>
+__device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+    const DNode *nd = nodes + tv.cur;
     const uint32_t flags = nd->flags;
     const int32_t c0 = nd->child[0], c1 = nd->child[1];
     double b0[6], b1[6];
@@ -275,16 +309,7 @@ __device__ __forceinline__ void node_step(const DScene &sc, const RayCtx &r, dou
     const bool none = tv.bp < 0;
     const bool h0 = box_test(b0, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || none || e0 <= tv.bt);
     const bool h1 = box_test(b1, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || none || e1 <= tv.bt);
-    const bool near0 = e0 <= e1;
-    if (h0 && h1) {
-        stack[tv.sp * stride] = near0 ? c1 : c0;
-        ++tv.sp;
-        tv.cur = near0 ? c0 : c1;
-    } else if (h0 || h1) {
-        tv.cur = h0 ? c0 : c1;
-    } else {
-        tv.cur = trav_pop(tv, stack, stride);
-    }
+    node_decide<SPILL>(c0, c1, h0, h1, e0, e1, st, tv);
 }
 
 // Records of the LDS copy of the tree.  The strides are chosen so that lanes reading the
@@ -293,31 +318,20 @@ __device__ __forceinline__ void node_step(const DScene &sc, const RayCtx &r, dou
 constexpr uint32_t LNODE_STRIDE = 120;   // bx[2][6] | child[2] | flags | pad
 constexpr uint32_t LPRIM_STRIDE = 88;    // c0[3] r dc[3] t0 t1 | mat kind orig pad
 
-// Where a walk finds the tree: device memory, or the block's LDS copy.
+// Where a walk finds the tree.  The block's LDS holds the first n_lnodes nodes (all of them
+// when the tree fits, else its top levels: nodes are numbered breadth-first there) and,
+// when lprims is set, every sphere; the rest is read from device memory.
 struct TreeView {
     const DNode *nodes;     // device memory
     const DPrim *prims;
-    const char *lnodes;     // LDS copies (null when the tree does not fit)
+    const char *lnodes;     // LDS copies
     const char *lprims;
+    int32_t n_lnodes;
 };
 
-__device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, bool h1, double e0, double e1, int *stack,
-                                            int stride, Trav &tv) {
-    const bool near0 = e0 <= e1;
-    if (h0 && h1) {
-        stack[tv.sp * stride] = near0 ? c1 : c0;
-        ++tv.sp;
-        tv.cur = near0 ? c0 : c1;
-    } else if (h0 || h1) {
-        tv.cur = h0 ? c0 : c1;
-    } else {
-        tv.cur = trav_pop(tv, stack, stride);
-    }
-}
-
 // node_step on the LDS copy
-__device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &r, double tmin, double tmax, int *stack,
-                                              int stride, Trav &tv) {
+template <bool SPILL>
+__device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
     const char *nd = lnodes + (uint32_t)tv.cur * LNODE_STRIDE;
     const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 96), c1 = *reinterpret_cast<const int32_t *>(nd + 100);
     const uint32_t flags = *reinterpret_cast<const uint32_t *>(nd + 104);
@@ -325,12 +339,12 @@ __device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &
     const bool none = tv.bp < 0;
     const bool h0 = box_test_ordered(nd, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || none || e0 <= tv.bt);
     const bool h1 = box_test_ordered(nd + 48, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || none || e1 <= tv.bt);
-    node_decide(c0, c1, h0, h1, e0, e1, stack, stride, tv);
+    node_decide<SPILL>(c0, c1, h0, h1, e0, e1, st, tv);
 }
 
-__device__ __forceinline__ void leaf_candidate(const DScene &sc, int32_t prim, bool moving, const RayCtx &r,
+__device__ __forceinline__ void leaf_candidate(const DPrim *prims, int32_t prim, bool moving, const RayCtx &r,
                                                double tmin, double tmax, Trav &tv) {
-    const DPrim *p = sc.prims + prim;
+    const DPrim *p = prims + prim;
     double t;
     if (sphere_root(prim_centre(p, moving, r.time), p->r, r, tmin, tmax, t)) {
         if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; }
@@ -353,24 +367,24 @@ __device__ __forceinline__ void leaf_candidate_lds(const char *lprims, int32_t p
     }
 }
 
-__device__ __forceinline__ void leaf_step_lds(const char *lprims, const RayCtx &r, double tmin, double tmax, const int *stack,
-                                              int stride, Trav &tv) {
+template <bool SPILL>
+__device__ __forceinline__ void leaf_step_lds(const char *lprims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
     const int32_t ref = tv.cur;
     const int32_t first = ref & LEAF_INDEX_MASK;
     leaf_candidate_lds(lprims, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
     if (ref & LEAF_TWO) leaf_candidate_lds(lprims, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
-    tv.cur = trav_pop(tv, stack, stride);
+    tv.cur = trav_pop<SPILL>(tv, st);
 }
 
 // One leaf: its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the
 // next stack entry.
-__device__ __forceinline__ void leaf_step(const DScene &sc, const RayCtx &r, double tmin, double tmax, const int *stack,
-                                          int stride, Trav &tv) {
+template <bool SPILL>
+__device__ __forceinline__ void leaf_step(const DPrim *prims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
     const int32_t ref = tv.cur;
     const int32_t first = ref & LEAF_INDEX_MASK;
-    leaf_candidate(sc, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
-    if (ref & LEAF_TWO) leaf_candidate(sc, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
-    tv.cur = trav_pop(tv, stack, stride);
+    leaf_candidate(prims, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
+    if (ref & LEAF_TWO) leaf_candidate(prims, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    tv.cur = trav_pop<SPILL>(tv, st);
 }
 
 // Starts the walk of one world item: tests the root box as bvh_node::hit does first
@@ -393,14 +407,15 @@ __device__ __forceinline__ bool item_begin(const DScene &sc, uint32_t item, cons
 // with a strictly nearer one (sphere_root's t < tmax).
 __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r, double tmin, double tmax,
                                               int *stack, int stride, double &t_out, int &prim_out) {
+    const LaneStack st = {stack, stride, 0, nullptr, 0};   // whole stack in LDS
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
         Trav tv;
         if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
         while (tv.cur != REF_NONE) {
-            if (tv.cur >= 0) node_step(sc, r, tmin, closest, stack, stride, tv);
-            else leaf_step(sc, r, tmin, closest, stack, stride, tv);
+            if (tv.cur >= 0) node_step<false>(sc.nodes, r, tmin, closest, st, tv);
+            else leaf_step<false>(sc.prims, r, tmin, closest, st, tv);
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }
@@ -414,9 +429,14 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 // sphere code for a handful of lanes each time.  Instead the wave counts, per iteration,
 // how many of its walking lanes stand at a leaf: the leaf body runs only when at least
 // LEAF_QUORUM lanes wait for it (or nobody wants a node); otherwise the node body runs.
+//
+// LDS_TREE: nodes and spheres are all in LDS and the stack never spills.  Otherwise the
+// first tree.n_lnodes nodes are in LDS, deeper nodes and all spheres in device memory, and
+// stack entries beyond st.cap spill to device memory.
 template <int LEAF_QUORUM, bool LDS_TREE>
 __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
-                                                    double tmax, int *stack, int stride, double &t_out, int &prim_out) {
+                                                    double tmax, const LaneStack &st, double &t_out, int &prim_out) {
+    constexpr bool SPILL = !LDS_TREE;
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
@@ -428,13 +448,13 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
             const int n_leaf = __popcll(__ballot(!at_node));
             if (n_leaf >= LEAF_QUORUM || n_node == 0) {
                 if (!at_node) {
-                    if (LDS_TREE) leaf_step_lds(tree.lprims, r, tmin, closest, stack, stride, tv);
-                    else leaf_step(sc, r, tmin, closest, stack, stride, tv);
+                    if (LDS_TREE) leaf_step_lds<SPILL>(tree.lprims, r, tmin, closest, st, tv);
+                    else leaf_step<SPILL>(tree.prims, r, tmin, closest, st, tv);
                 }
             } else {
                 if (at_node) {
-                    if (LDS_TREE) node_step_lds(tree.lnodes, r, tmin, closest, stack, stride, tv);
-                    else node_step(sc, r, tmin, closest, stack, stride, tv);
+                    if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin, closest, st, tv);
+                    else node_step<SPILL>(tree.nodes, r, tmin, closest, st, tv);
                 }
             }
         }

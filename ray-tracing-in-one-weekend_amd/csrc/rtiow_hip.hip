@@ -129,35 +129,40 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // A finished path adds its radiance to the tile's sums in LDS; the random stream is
 // keyed by (pixel, sample), so the set of paths -- and every path's arithmetic -- is
 // independent of which lane ran it.
-#ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 3          // waves per SIMD the kernel is compiled for
-#endif
 #ifndef RT_LEAF_QUORUM
 #define RT_LEAF_QUORUM 4
 #endif
-constexpr int kRenderBlock = 256 * RT_RENDER_WAVES;   // one block fills a CU
-constexpr int kRenderWaves = kRenderBlock / 64;
+// Two shapes of the kernel.  When nodes, spheres and full-depth stacks fit in LDS the block
+// is 768 threads (3 waves per SIMD) and every traversal step reads LDS.  Otherwise the block
+// is 1024 threads (the walk then waits on device memory, and a fourth wave per SIMD hides
+// more of it), LDS holds the top levels of the tree -- the first n_lnodes nodes, which are
+// numbered breadth-first -- and the first stack_cap entries of each lane's stack; deeper
+// nodes and all spheres are read from device memory, deeper stack entries spill to it.
+constexpr int kWavesLdsTree = 3, kWavesDeviceTree = 4;   // waves per SIMD
+constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 
-template <class AccT, bool LDS_TREE>
-__global__ __launch_bounds__(kRenderBlock) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
-                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
-                                                        AccT *accum, unsigned long long *counters, uint32_t n_nodes,
-                                                        uint32_t n_prims) {
+template <class AccT, bool LDS_TREE, int WAVES>
+__global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
+                                                       uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
+                                                       AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
+                                                       uint32_t n_lprims, uint32_t stack_cap, int *spill) {
+    constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // LDS: [tile sums: waves x 64 px x rgb doubles][stacks: depth x block ints][tree copy]
+    // LDS: [tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][spheres]
     double *tile_sum = reinterpret_cast<double *>(lds_raw) + wave * 192;
-    int *stack = reinterpret_cast<int *>(lds_raw + kRenderWaves * 192 * sizeof(double)) + tid;
-    char *ltree = lds_raw + kRenderWaves * 192 * sizeof(double) + (size_t)sc.stack_depth * kRenderBlock * sizeof(int);
-    TreeView tree = {sc.nodes, sc.prims, nullptr, nullptr};
-    if (LDS_TREE) {
-        char *lnodes = ltree, *lprims = ltree + (size_t)n_nodes * LNODE_STRIDE;
-        for (uint32_t i = tid; i < n_nodes * 15u; i += kRenderBlock) {   // 15 doubles of a node record are copied
+    char *ltree = lds_raw + kRenderWaves * 192 * sizeof(double) + (size_t)stack_cap * kRenderBlock * sizeof(int);
+    const LaneStack st = {reinterpret_cast<int *>(lds_raw + kRenderWaves * 192 * sizeof(double)) + tid, kRenderBlock, (int)stack_cap,
+                          spill ? spill + (size_t)blockIdx.x * kRenderBlock + tid : nullptr, (int)(gridDim.x * kRenderBlock)};
+    TreeView tree = {sc.nodes, sc.prims, nullptr, nullptr, (int32_t)n_lnodes};
+    {
+        char *lnodes = ltree, *lprims = ltree + (size_t)n_lnodes * LNODE_STRIDE;
+        for (uint32_t i = tid; i < n_lnodes * 15u; i += kRenderBlock) {   // 15 doubles of a node record are copied
             const uint32_t n = i / 15u, w = i % 15u;
             const double *src = reinterpret_cast<const double *>(sc.nodes + n);
             reinterpret_cast<double *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = src[w];
         }
-        for (uint32_t i = tid; i < n_prims * 11u; i += kRenderBlock) {   // 11 doubles of a sphere record
+        for (uint32_t i = tid; i < n_lprims * 11u; i += kRenderBlock) {   // 11 doubles of a sphere record
             const uint32_t n = i / 11u, w = i % 11u;
             const double *src = reinterpret_cast<const double *>(sc.prims + n);
             reinterpret_cast<double *>(lprims + (size_t)n * LPRIM_STRIDE)[w] = src[w];
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(kRenderBlock) void k_render(DScene sc, DCamera cam,
                 double t;
                 int prim;
                 ++nrays;
-                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE>(sc, tree, ctx, t_min, DBL_MAX, stack, kRenderBlock, t, prim)) {
+                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim)) {
                     v3 p, nn, att;
                     Ray nextray;
                     hit_point(sc, prim, ctx, t, p, nn);
@@ -311,7 +316,12 @@ struct rt_scene {
     dev_buf<unsigned long long> counter;
     std::vector<uint32_t> material_of_prim;  // by description index
     uint32_t n_prims_desc = 0, n_textures = 0;
-    size_t lds_bytes = 0, render_lds_bytes = 0, render_lds_tree_bytes = 0;
+    dev_buf<int> spill;                      // stack entries beyond the LDS part, per render lane
+    size_t lds_bytes = 0;                    // stacks of the batch kernels
+    // shape of the render kernel for this scene (see k_render)
+    bool render_lds_tree = false;
+    uint32_t render_lnodes = 0, render_lprims = 0, render_stack_cap = 0;
+    size_t render_lds_bytes = 0;
     uint32_t n_nodes_dev = 0, n_prims_dev = 0;
     int n_cus = 256;
 };
@@ -527,6 +537,36 @@ struct flattener {
         return me;
     }
 
+    // Renumbers the nodes so that the k nearest to the roots, breadth-first, come first (the
+    // part of a large tree the render kernel keeps in LDS); the others keep their order.
+    void stage_top_levels(size_t k, std::vector<DItem> &items) {
+        const size_t n = nodes.size();
+        if (k > n) k = n;
+        std::vector<int32_t> renum(n, -1);
+        std::vector<int32_t> order;
+        order.reserve(k);
+        for (const DItem &it : items)
+            if (it.ref >= 0 && order.size() < k && renum[it.ref] < 0) { renum[it.ref] = (int32_t)order.size(); order.push_back(it.ref); }
+        for (size_t head = 0; head < order.size() && order.size() < k; ++head)
+            for (int c = 0; c < 2; ++c) {
+                const int32_t ch = nodes[order[head]].child[c];
+                if (ch >= 0 && order.size() < k && renum[ch] < 0) { renum[ch] = (int32_t)order.size(); order.push_back(ch); }
+            }
+        int32_t next = (int32_t)order.size();
+        for (size_t i = 0; i < n; ++i)
+            if (renum[i] < 0) renum[i] = next++;
+        std::vector<DNode> moved(n);
+        for (size_t i = 0; i < n; ++i) {
+            DNode nd = nodes[i];
+            for (int c = 0; c < 2; ++c)
+                if (nd.child[c] >= 0) nd.child[c] = renum[nd.child[c]];
+            moved[renum[i]] = nd;
+        }
+        nodes.swap(moved);
+        for (DItem &it : items)
+            if (it.ref >= 0) it.ref = renum[it.ref];
+    }
+
     // the whole bvh item rooted at description node `id`, re-clustered
     int32_t build_clustered(int32_t id, bool &safe) {
         leaves.clear();
@@ -617,6 +657,40 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     rt_scene *s = new (std::nothrow) rt_scene;
     if (!s) return fail(RT_E_INVALID, "out of host memory");
     s->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
+    }
+    // shape of the render kernel: everything in LDS when it fits, else the top levels only
+    const uint32_t stack_depth = fl.max_depth + 2;
+    size_t spill_ints = 0;
+    {
+        const size_t sums = 192 * sizeof(double);   // per wave
+        const size_t whole = 4 * kWavesLdsTree * sums + (size_t)stack_depth * 256 * kWavesLdsTree * sizeof(int) +
+                             fl.nodes.size() * LNODE_STRIDE + fl.prims.size() * LPRIM_STRIDE;
+        // RTIOW_RENDER_LDS_NODES=k forces the large-tree shape with at most k nodes staged and
+        // RTIOW_RENDER_STACK_CAP=c its LDS stack entries, so that small scenes can exercise
+        // the staged walk and the spilling stack in tests.
+        const char *force_nodes = getenv("RTIOW_RENDER_LDS_NODES"), *force_cap = getenv("RTIOW_RENDER_STACK_CAP");
+        if (whole <= kLdsBudget && !force_nodes) {
+            s->render_lds_tree = true;
+            s->render_lnodes = (uint32_t)fl.nodes.size();
+            s->render_lprims = (uint32_t)fl.prims.size();
+            s->render_stack_cap = stack_depth;
+            s->render_lds_bytes = whole;
+        } else {
+            uint32_t cap = std::min<uint32_t>(stack_depth, kSpillStackCap);
+            if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(1, atoi(force_cap)));
+            const size_t base = 4 * kWavesDeviceTree * sums + (size_t)cap * 256 * kWavesDeviceTree * sizeof(int);
+            size_t k = std::min(fl.nodes.size(), (kLdsBudget - base) / LNODE_STRIDE);
+            if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
+            fl.stage_top_levels(k, items);
+            s->render_lnodes = (uint32_t)k;
+            s->render_stack_cap = cap;
+            s->render_lds_bytes = base + k * LNODE_STRIDE;
+            spill_ints = (size_t)(stack_depth - cap) * s->n_cus * 256 * kWavesDeviceTree;
+        }
+    }
     s->n_prims_desc = desc->n_prims;
     s->n_textures = desc->n_textures;
     s->material_of_prim.resize(desc->n_prims);
@@ -658,11 +732,14 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->ranfloat.upload(ranfloat.data(), ranfloat.size());
     if (e == hipSuccess) e = s->perm.upload(perm.data(), perm.size());
     if (e == hipSuccess) e = s->counter.alloc(2);
+    if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
     // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    const void *kernels[4] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesLdsTree>),
+                              reinterpret_cast<const void *>(&k_render<double, true, kWavesLdsTree>),
+                              reinterpret_cast<const void *>(&k_render<float, false, kWavesDeviceTree>),
+                              reinterpret_cast<const void *>(&k_render<double, false, kWavesDeviceTree>)};
+    for (const void *k : kernels)
+        if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) {
         delete s;
         return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
@@ -670,20 +747,16 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->d.nodes = s->nodes.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
-    s->d.stack_depth = fl.max_depth + 2;
+    s->d.stack_depth = stack_depth;
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);
     s->n_nodes_dev = (uint32_t)fl.nodes.size();
     s->n_prims_dev = (uint32_t)fl.prims.size();
-    s->render_lds_bytes = (size_t)s->d.stack_depth * kRenderBlock * sizeof(int) + kRenderWaves * 192 * sizeof(double);
-    s->render_lds_tree_bytes = s->render_lds_bytes + (size_t)s->n_nodes_dev * LNODE_STRIDE + (size_t)s->n_prims_dev * LPRIM_STRIDE;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
-    }
     if (getenv("RTIOW_VERBOSE"))
-        fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render LDS %zu B without / %zu B with the tree (budget %zu)\n",
+        fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render kernel: %s, %u nodes and %u spheres in LDS, "
+                        "%u stack entries in LDS, %zu B of LDS (budget %zu), %zu B of spill\n",
                 fl.nodes.size(), fl.prims.size(), fl.max_depth, reference_layout ? "reference" : "re-clustered",
-                s->render_lds_bytes, s->render_lds_tree_bytes, kLdsBudget);
+                s->render_lds_tree ? "whole tree in LDS" : "top levels in LDS", s->render_lnodes, s->render_lprims,
+                s->render_stack_cap, s->render_lds_bytes, kLdsBudget, spill_ints * sizeof(int));
     *out = s;
     return RT_OK;
 }
@@ -820,7 +893,6 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     if (pr->sample_end < pr->sample_begin) return fail(RT_E_INVALID, "rt_render: sample_end < sample_begin");
     if (pr->sample_end - pr->sample_begin > (1u << 24)) return fail(RT_E_INVALID, "rt_render: more than 2^24 samples per pixel in one call");
     if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render: unknown accum_type %u", pr->accum_type);
-    if (scene->render_lds_bytes > kLdsBudget) return fail(RT_E_UNSUPPORTED, "rt_render: traversal stacks need %zu bytes of LDS", scene->render_lds_bytes);
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -832,17 +904,19 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     const uint32_t n_tiles = ((pr->nx + 7) / 8) * ((pr->ny + 7) / 8);
-    const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + kRenderWaves - 1) / kRenderWaves);
-    dim3 grid(blocks), block(kRenderBlock);
+    const uint32_t waves = 4 * (scene->render_lds_tree ? kWavesLdsTree : kWavesDeviceTree);
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
+    dim3 grid(blocks), block(64 * waves);
     DCamera cam = to_dcamera(camera);
-    const bool lds_tree = scene->render_lds_tree_bytes <= kLdsBudget;
-    const size_t lds = lds_tree ? scene->render_lds_tree_bytes : scene->render_lds_bytes;
-#define RT_LAUNCH(T, L)                                                                                                  \
-    hipLaunchKernelGGL((k_render<T, L>), grid, block, lds, stream, scene->d, cam, pr->nx, pr->ny, pr->sample_begin,         \
-                       pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (T *)accum_dev, scene->counter.p,               \
-                       scene->n_nodes_dev, scene->n_prims_dev)
-    if (pr->accum_type == RT_ACCUM_F32) { if (lds_tree) RT_LAUNCH(float, true); else RT_LAUNCH(float, false); }
-    else { if (lds_tree) RT_LAUNCH(double, true); else RT_LAUNCH(double, false); }
+#define RT_LAUNCH(T, L, W)                                                                                                \
+    hipLaunchKernelGGL((k_render<T, L, W>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
+                       pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (T *)accum_dev, scene->counter.p, \
+                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p)
+    if (scene->render_lds_tree) {
+        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, true, kWavesLdsTree); else RT_LAUNCH(double, true, kWavesLdsTree);
+    } else {
+        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, false, kWavesDeviceTree); else RT_LAUNCH(double, false, kWavesDeviceTree);
+    }
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (stats) {

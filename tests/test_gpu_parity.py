@@ -308,6 +308,35 @@ def test_reclustered_tree_equals_reference_layout(rt, scene, monkeypatch):
     w_new.close()
 
 
+@pytest.mark.parametrize("scene,lds_nodes,stack_cap", [("book1", 40, 3), ("book2", 0, 1), ("stress4096", 300, 4), ("mixed", 7, 2)])
+def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stack_cap, monkeypatch):
+    # Trees too large for LDS keep only their top levels (breadth-first) there and spill deep stack
+    # entries to device memory.  Forcing that shape on scenes the oracle renders in seconds: frames
+    # must equal the oracle's and the all-in-LDS shape's, whatever the split.
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = 2.0
+    w_lds = rt.World(recipe(scene))
+    monkeypatch.setenv("RTIOW_RENDER_LDS_NODES", str(lds_nodes))
+    monkeypatch.setenv("RTIOW_RENDER_STACK_CAP", str(stack_cap))
+    w_big = rt.World(recipe(scene))
+    monkeypatch.delenv("RTIOW_RENDER_LDS_NODES")
+    monkeypatch.delenv("RTIOW_RENDER_STACK_CAP")
+    try:
+        fa, sa = w_lds.render(rt.camera(cam15), 72, 36, 0, 5, 21)
+        fb, sb = w_big.render(rt.camera(cam15), 72, 36, 0, 5, 21)
+        exp, counters = orc.Scene(recipe(scene)).render(cam15, 72, 36, 0, 5, 21, orc.ORC_RNG_STREAM)
+        assert sa.rays == sb.rays == counters.rays
+        assert np.array_equal(fa, fb)
+        np.testing.assert_allclose(fb, exp, rtol=1e-11, atol=1e-13)
+        g = golden("trace_" + scene)      # the batch walk reads the renumbered tree too
+        a = w_lds.trace(g["rays"], float(g["tmin"]), float(g["tmax"]))
+        b = w_big.trace(g["rays"], float(g["tmin"]), float(g["tmax"]))
+        assert a.tobytes() == b.tobytes()
+    finally:
+        w_lds.close()
+        w_big.close()
+
+
 EDGE_FRAMES = [
     # nx, ny, first sample, one past the last, max depth, aperture
     (1, 1, 0, 3, 50, 0.0),        # a single pixel: one ragged tile
