@@ -493,14 +493,33 @@ __device__ __forceinline__ double perlin_noise(const DScene &sc, v3 p) {
     return accum;
 }
 
+// The chequer (texture.cpp:10-13) only asks whether sin(ax) sin(ay) sin(az) < 0.  No factor of
+// a finite non-zero argument is zero and the product cannot underflow, so that is "an odd
+// number of negative factors", and sin(a) < 0 exactly when floor(a / pi) is odd.  With
+// q = a * RN(1/pi), |q - a/pi| <= |a/pi| 2^-51.9 < 2^-32 for |a| < 2^21; when q is farther
+// than 2^-29 from an integer, floor(q) = floor(a/pi) and the sign is known from 4 operations
+// instead of a full sin().  `sure` is cleared when that cannot be concluded (a near a multiple
+// of pi, huge, zero or not finite).
+__device__ __forceinline__ bool sine_is_negative(double a, bool &sure) {
+    const double q = a * 0.31830988618379067154;
+    const double n = __builtin_rint(q);
+    const double d = q - n;
+    if (!(__builtin_fabs(a) < 2097152.0 && __builtin_fabs(d) > 0x1p-29)) sure = false;
+    return (((int)n & 1) != 0) != (d < 0);
+}
+
 // texture.hpp:19, texture.cpp:10-18.  Chequer children index earlier table entries, so
 // the walk ends.
 __device__ __forceinline__ v3 texture_value(const DScene &sc, uint32_t tex, v3 p) {
     const DTex *t = sc.texs + tex;
     if (t->kind == RT_TEX_CHEQUER) {
-        double sines = sin(10 * p.x) * sin(10 * p.y) * sin(10 * p.z);
+        const double ax = 10 * p.x, ay = 10 * p.y, az = 10 * p.z;
+        bool sure = true;
+        bool odd = sine_is_negative(ax, sure) != sine_is_negative(ay, sure);
+        odd = odd != sine_is_negative(az, sure);
+        if (!sure) odd = sin(ax) * sin(ay) * sin(az) < 0;
         do {
-            t = sc.texs + (sines < 0 ? t->odd : t->even);
+            t = sc.texs + (odd ? t->odd : t->even);
         } while (t->kind == RT_TEX_CHEQUER);
     }
     if (t->kind == RT_TEX_PERLIN) {

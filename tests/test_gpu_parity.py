@@ -124,6 +124,30 @@ def test_textures(worlds):
     assert np.array_equal(cheq, g["chequer"])
 
 
+def test_chequer_near_the_zeros_of_sine(orc, worlds):
+    # The chequer uses the sign of sin(10x) sin(10y) sin(10z) (texture.cpp:10-13).  Points whose
+    # coordinates put 10x within a few ulps of a multiple of pi, at zero, far out, or not finite
+    # are where a shortcut for the sign would go wrong first.
+    rng = np.random.default_rng(5)
+    k = np.concatenate([np.arange(-40, 41), rng.integers(-600000, 600000, 400)]).astype(np.float64)
+    near = k * np.pi / 10
+    xs = [near]
+    for _ in range(3):
+        xs.append(np.nextafter(xs[-1], np.inf))
+    lo = near
+    for _ in range(3):
+        lo = np.nextafter(lo, -np.inf)
+        xs.append(lo)
+    special = np.array([0.0, -0.0, 1e-310, -1e-310, 2e5, 209715.2, 209715.3, 1e7, -3e9, 1e300, np.inf, -np.inf, np.nan])
+    x = np.concatenate(xs + [special, rng.uniform(-50, 50, 2000)])
+    pts = np.stack([x, rng.permutation(x), rng.uniform(-20, 20, len(x))], axis=1)
+    pts = np.concatenate([pts, pts[:, [2, 0, 1]], pts[:, [1, 2, 0]]])
+    got = worlds("book2").texture(2, pts)
+    exp = orc.Scene(recipe("book2")).texture(2, pts)
+    assert np.array_equal(got, exp)
+    assert len(np.unique(got[:, 0])) == 2          # both colours occur
+
+
 @pytest.mark.parametrize("scene", ["book2", "mixed"])
 def test_scatter(worlds, scene):
     g = golden("scatter_" + scene)
