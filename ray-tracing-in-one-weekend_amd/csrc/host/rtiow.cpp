@@ -545,6 +545,21 @@ void frame::write_ppm(std::FILE* out) const {
         }
 }
 
+// The same bytes as raw P6: at 3840x2160 the P3 text is ~100 MB, the binary file 25 MB.
+void frame::write_ppm_binary(std::FILE* out) const {
+    std::fprintf(out, "P6\n%d %d\n255\n", nx, ny);
+    std::vector<unsigned char> row((size_t)nx * 3);
+    for (int r = 0; r < ny; ++r) {
+        for (int i = 0; i < nx; ++i) {
+            colour const c = pixel(i, r);
+            row[(size_t)i * 3] = (unsigned char)int(255.99 * c.red());
+            row[(size_t)i * 3 + 1] = (unsigned char)int(255.99 * c.green());
+            row[(size_t)i * 3 + 2] = (unsigned char)int(255.99 * c.blue());
+        }
+        std::fwrite(row.data(), 1, row.size(), out);
+    }
+}
+
 // ------------------------------------------------------------- scene builders ----
 // main.cpp:52-59
 object_list two_perlin_spheres(std::mt19937& mt) {

@@ -20,7 +20,7 @@ using namespace rtiow;
 static int usage() {
     std::fprintf(stderr,
                  "usage: raytracer [--scene two_perlin|book1|book2|stress|FILE.recipe] [--nx N] [--ny N] [--ns N]\n"
-                 "                 [--seed S] [--scene-seed S] [--spheres N] [--device D] [--aperture A] [--out FILE.ppm]\n");
+                 "                 [--seed S] [--scene-seed S] [--spheres N] [--device D] [--aperture A] [--out FILE.ppm] [--binary]\n");
     return 2;
 }
 
@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     uint32_t scene_seed = 1;
     int spheres = 1000000;
     double aperture = 0;
+    bool binary = false;   // P6 instead of the reference's P3 text
     for (int i = 1; i < argc; ++i) {
         std::string const a = argv[i];
         auto need = [&](char const* name) -> char const* {
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") opt.device = std::atoi(need("--device"));
         else if (a == "--aperture") aperture = std::atof(need("--aperture"));
         else if (a == "--out") out_path = need("--out");
+        else if (a == "--binary") binary = true;
         else return usage();
     }
     try {
@@ -67,9 +69,9 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "Render duration: %gs\n", secs);
         std::fprintf(stderr, "kernel %.3f ms, %.3f Mpaths/s, %.3f rays/path\n", f.stats.kernel_ms,
                      (double)f.stats.paths / (f.stats.kernel_ms * 1e3), (double)f.stats.rays / (double)f.stats.paths);
-        std::FILE* out = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "w");
+        std::FILE* out = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "wb");
         if (!out) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 1; }
-        f.write_ppm(out);
+        if (binary) f.write_ppm_binary(out); else f.write_ppm(out);
         if (out != stdout) std::fclose(out);
     } catch (std::exception const& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
