@@ -140,12 +140,14 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // nodes and all spheres are read from device memory, deeper stack entries spill to it.
 constexpr int kWavesLdsTree = 3, kWavesDeviceTree = 4;   // waves per SIMD
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
+constexpr uint32_t kOrderMinSamples = 32;               // frames at least this deep get their tiles ordered by cost
 
 template <class AccT, bool LDS_TREE, int WAVES>
 __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
-                                                       uint32_t n_lprims, uint32_t stack_cap, int *spill) {
+                                                       uint32_t n_lprims, uint32_t stack_cap, int *spill,
+                                                       const uint32_t *tile_order, uint32_t *tile_cost) {
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -176,9 +178,13 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
 
     for (;;) {
         uint32_t tile = 0;
-        if (lane == 0) tile = (uint32_t)atomicAdd(counters + 1, 1ull);
+        if (lane == 0) {
+            tile = (uint32_t)atomicAdd(counters + 1, 1ull);
+            if (tile < n_tiles && tile_order) tile = tile_order[tile];
+        }
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= n_tiles) break;
+        const long long tile_start = tile_cost ? wall_clock64() : 0;
         const uint32_t tile_x = (tile % tiles_x) * 8, tile_y = (tile / tiles_x) * 8;
         const uint32_t total = 64u * (s_end - s_begin);
         uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
@@ -247,6 +253,12 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                 }
             }
         }
+        if (tile_cost) {
+            // costing pass: the image is not touched, the tile's duration is what is wanted
+            const long long ticks = wall_clock64() - tile_start;
+            if (lane == 0) tile_cost[tile] = (uint32_t)(ticks < 0 ? 0 : (ticks > 0x7FFFFFFFll ? 0x7FFFFFFFll : ticks));
+            continue;
+        }
         const uint32_t x = tile_x + (lane & 7u), y = tile_y + (lane >> 3);
         if (x < nx && y < ny) {
             AccT *a = accum + ((size_t)y * nx + x) * 3;
@@ -265,6 +277,35 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float *accum, size_t n
     double mean = spp ? (double)accum[i] / (double)spp : 0.0;
     int q = (int)(255.99 * sqrt(mean));
     rgb8[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+
+// Orders the tiles of a frame by measured cost, dearest first (a counting sort over 1024
+// cost classes in one block; ties in arbitrary order).  A wave works through a tile's whole
+// sample range, and tiles differ in cost by an order of magnitude (sky against glass), so
+// handing them out in image order leaves a few waves finishing the last, dear tiles while
+// the rest of the chip idles; longest-first keeps the end of the frame to the cheap ones.
+constexpr int kOrderBlock = 1024;
+__global__ __launch_bounds__(kOrderBlock) void k_order_tiles(const uint32_t *cost, uint32_t n, uint32_t *order) {
+    __shared__ uint32_t hist[kOrderBlock];
+    __shared__ uint32_t cmax;
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) cmax = 1;
+    __syncthreads();
+    uint32_t m = 1;
+    for (uint32_t i = tid; i < n; i += kOrderBlock) m = cost[i] > m ? cost[i] : m;
+    atomicMax(&cmax, m);
+    __syncthreads();
+    const unsigned long long top = cmax;
+    for (uint32_t i = tid; i < n; i += kOrderBlock) atomicAdd(&hist[(uint32_t)((unsigned long long)cost[i] * (kOrderBlock - 1) / top)], 1u);
+    __syncthreads();
+    if (tid == 0) {   // start of each class in the output, dearest class first
+        uint32_t at = 0;
+        for (int b = kOrderBlock - 1; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = at; at += c; }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kOrderBlock)
+        order[atomicAdd(&hist[(uint32_t)((unsigned long long)cost[i] * (kOrderBlock - 1) / top)], 1u)] = i;
 }
 
 }  // namespace
@@ -317,6 +358,8 @@ struct rt_scene {
     std::vector<uint32_t> material_of_prim;  // by description index
     uint32_t n_prims_desc = 0, n_textures = 0;
     dev_buf<int> spill;                      // stack entries beyond the LDS part, per render lane
+    dev_buf<uint32_t> tiles;                 // per tile: measured cost, then the render order
+    size_t tiles_capacity = 0;
     size_t lds_bytes = 0;                    // stacks of the batch kernels
     // shape of the render kernel for this scene (see k_render)
     bool render_lds_tree = false;
@@ -731,7 +774,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->texs.upload(texs.data(), texs.size());
     if (e == hipSuccess) e = s->ranfloat.upload(ranfloat.data(), ranfloat.size());
     if (e == hipSuccess) e = s->perm.upload(perm.data(), perm.size());
-    if (e == hipSuccess) e = s->counter.alloc(2);
+    if (e == hipSuccess) e = s->counter.alloc(4);
     if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
     // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
     const void *kernels[4] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesLdsTree>),
@@ -896,27 +939,51 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // counters[0] = rays traced, counters[1] = next tile of the frame
-    HIP_TRY(hipMemsetAsync(scene->counter.p, 0, 2 * sizeof(unsigned long long), stream));
+    const uint32_t n_tiles = ((pr->nx + 7) / 8) * ((pr->ny + 7) / 8);
+    const uint32_t waves = 4 * (scene->render_lds_tree ? kWavesLdsTree : kWavesDeviceTree);
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
+    const uint32_t spp = pr->sample_end - pr->sample_begin;
+    // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
+    // the pass traces 1 (or 2) samples per pixel without touching the image, ~1/spp of the work.
+    const bool ordered = spp >= kOrderMinSamples && n_tiles >= 2 * blocks * waves && !getenv("RTIOW_TILE_ORDER_OFF");
+    if (ordered && scene->tiles_capacity < 2 * (size_t)n_tiles) {
+        if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
+        HIP_TRY(scene->tiles.alloc(2 * (size_t)n_tiles));
+        scene->tiles_capacity = 2 * (size_t)n_tiles;
+    }
+    // counters[0] = rays traced, counters[1] = next tile of the frame; [2], [3]: the same for the costing pass
+    HIP_TRY(hipMemsetAsync(scene->counter.p, 0, 4 * sizeof(unsigned long long), stream));
     if (stats) {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    const uint32_t n_tiles = ((pr->nx + 7) / 8) * ((pr->ny + 7) / 8);
-    const uint32_t waves = 4 * (scene->render_lds_tree ? kWavesLdsTree : kWavesDeviceTree);
-    const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
     dim3 grid(blocks), block(64 * waves);
     DCamera cam = to_dcamera(camera);
-#define RT_LAUNCH(T, L, W)                                                                                                \
+#define RT_LAUNCH(T, L, W, S_END, ACCUM, COUNTERS, ORDER, COST)                                                           \
     hipLaunchKernelGGL((k_render<T, L, W>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
-                       pr->sample_begin, pr->sample_end, pr->max_depth, pr->t_min, pr->seed, (T *)accum_dev, scene->counter.p, \
-                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p)
-    if (scene->render_lds_tree) {
-        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, true, kWavesLdsTree); else RT_LAUNCH(double, true, kWavesLdsTree);
-    } else {
-        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, false, kWavesDeviceTree); else RT_LAUNCH(double, false, kWavesDeviceTree);
+                       pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
+                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST)
+#define RT_LAUNCH_SHAPE(S_END, ACCUM, COUNTERS, ORDER, COST)                                                              \
+    do {                                                                                                                  \
+        if (scene->render_lds_tree) {                                                                                     \
+            if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, true, kWavesLdsTree, S_END, ACCUM, COUNTERS, ORDER, COST); \
+            else RT_LAUNCH(double, true, kWavesLdsTree, S_END, ACCUM, COUNTERS, ORDER, COST);                             \
+        } else {                                                                                                          \
+            if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, false, kWavesDeviceTree, S_END, ACCUM, COUNTERS, ORDER, COST); \
+            else RT_LAUNCH(double, false, kWavesDeviceTree, S_END, ACCUM, COUNTERS, ORDER, COST);                         \
+        }                                                                                                                 \
+    } while (0)
+    const uint32_t *order = nullptr;
+    if (ordered) {
+        uint32_t *cost = scene->tiles.p, *sorted = scene->tiles.p + n_tiles;
+        const uint32_t probe = spp >= 8 * kOrderMinSamples ? 2u : 1u;
+        RT_LAUNCH_SHAPE(pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost);
+        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, n_tiles, sorted);
+        order = sorted;
     }
+    RT_LAUNCH_SHAPE(pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
+#undef RT_LAUNCH_SHAPE
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (stats) {

@@ -361,6 +361,22 @@ def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stac
         w_big.close()
 
 
+def test_cost_ordered_tiles_render_the_same_frame(rt, worlds, monkeypatch):
+    # Deep frames with many tiles get a costing pass and are rendered dearest tile first.  Which wave
+    # renders which tile when must not change a bit of the image or the ray count.
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = 800 / 640
+    w = worlds("book1")
+    for accum in (rt.RT_ACCUM_F64, rt.RT_ACCUM_F32):
+        ordered, s_ordered = w.render(rt.camera(cam15), 800, 640, 3, 3 + 32, 8, accum)
+        monkeypatch.setenv("RTIOW_TILE_ORDER_OFF", "1")
+        plain, s_plain = w.render(rt.camera(cam15), 800, 640, 3, 3 + 32, 8, accum)
+        monkeypatch.delenv("RTIOW_TILE_ORDER_OFF")
+        assert s_ordered.rays == s_plain.rays and s_ordered.paths == s_plain.paths == 800 * 640 * 32
+        assert np.array_equal(ordered, plain)
+        assert ordered.any()
+
+
 EDGE_FRAMES = [
     # nx, ny, first sample, one past the last, max depth, aperture
     (1, 1, 0, 3, 50, 0.0),        # a single pixel: one ragged tile
