@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
         }
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= n_tiles) break;
-        const long long tile_start = tile_cost ? wall_clock64() : 0;
+        uint32_t work = 0;   // per lane: traversal iterations and rounds it took part in (see world_closest_voted)
         const uint32_t tile_x = (tile % tiles_x) * 8, tile_y = (tile / tiles_x) * 8;
         const uint32_t total = 64u * (s_end - s_begin);
         uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                 double t;
                 int prim;
                 ++nrays;
-                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim)) {
+                work += 8;   // claiming, set-up and shading of one segment, in node-step units
+                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work)) {
                     v3 p, nn, att;
                     Ray nextray;
                     hit_point(sc, prim, ctx, t, p, nn);
@@ -254,9 +255,12 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
             }
         }
         if (tile_cost) {
-            // costing pass: the image is not touched, the tile's duration is what is wanted
-            const long long ticks = wall_clock64() - tile_start;
-            if (lane == 0) tile_cost[tile] = (uint32_t)(ticks < 0 ? 0 : (ticks > 0x7FFFFFFFll ? 0x7FFFFFFFll : ticks));
+            // costing pass: the image is not touched; the tile's cost is the work its busiest lane
+            // counted (a count, not a duration: durations depend on what else the CU is running)
+            uint32_t segs = work;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(segs, off); segs = o > segs ? o : segs; }
+            if (lane == 0) tile_cost[tile] = segs;
             continue;
         }
         const uint32_t x = tile_x + (lane & 7u), y = tile_y + (lane >> 3);
@@ -944,7 +948,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
     const uint32_t spp = pr->sample_end - pr->sample_begin;
     // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
-    // the pass traces 1 (or 2) samples per pixel without touching the image, ~1/spp of the work.
+    // the pass traces 1 to 4 samples per pixel without touching the image, under 2 % of the work.
     const bool ordered = spp >= kOrderMinSamples && n_tiles >= 2 * blocks * waves && !getenv("RTIOW_TILE_ORDER_OFF");
     if (ordered && scene->tiles_capacity < 2 * (size_t)n_tiles) {
         if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
@@ -977,7 +981,8 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     const uint32_t *order = nullptr;
     if (ordered) {
         uint32_t *cost = scene->tiles.p, *sorted = scene->tiles.p + n_tiles;
-        const uint32_t probe = spp >= 8 * kOrderMinSamples ? 2u : 1u;
+        uint32_t probe = std::min(4u, std::max(1u, spp / 64u));   // measured: 1 sample ranks noisily, more than 4 costs more than it saves
+        if (const char *e = getenv("RTIOW_TILE_PROBE")) probe = std::min<uint32_t>(spp, (uint32_t)std::max(1, atoi(e)));
         RT_LAUNCH_SHAPE(pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost);
         hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, n_tiles, sorted);
         order = sorted;
