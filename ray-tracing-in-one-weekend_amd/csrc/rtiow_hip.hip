@@ -132,13 +132,14 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 #ifndef RT_LEAF_QUORUM
 #define RT_LEAF_QUORUM 4
 #endif
-// Two shapes of the kernel.  When nodes, spheres and full-depth stacks fit in LDS the block
-// is 768 threads (3 waves per SIMD) and every traversal step reads LDS.  Otherwise the block
-// is 1024 threads (the walk then waits on device memory, and a fourth wave per SIMD hides
-// more of it), LDS holds the top levels of the tree -- the first n_lnodes nodes, which are
-// numbered breadth-first -- and the first stack_cap entries of each lane's stack; deeper
-// nodes and all spheres are read from device memory, deeper stack entries spill to it.
-constexpr int kWavesLdsTree = 3, kWavesDeviceTree = 4;   // waves per SIMD
+// Shapes of the kernel.  When nodes, spheres and full-depth stacks fit in LDS every traversal
+// step reads LDS; the block is 1024 threads (4 waves per SIMD, measured 4-5 % faster than 3)
+// if that still fits, else 768.  Otherwise the block is 1024 threads (the walk then waits on
+// device memory, which more waves hide), LDS holds the top levels of the tree -- the first
+// n_lnodes nodes, which are numbered breadth-first -- and the first stack_cap entries of each
+// lane's stack; deeper nodes and all spheres are read from device memory, deeper stack
+// entries spill to it.
+constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 constexpr uint32_t kOrderMinSamples = 32;               // frames at least this deep get their tiles ordered by cost
 
@@ -367,6 +368,7 @@ struct rt_scene {
     size_t lds_bytes = 0;                    // stacks of the batch kernels
     // shape of the render kernel for this scene (see k_render)
     bool render_lds_tree = false;
+    int render_waves = kWavesMin;            // per SIMD
     uint32_t render_lnodes = 0, render_lprims = 0, render_stack_cap = 0;
     size_t render_lds_bytes = 0;
     uint32_t n_nodes_dev = 0, n_prims_dev = 0;
@@ -713,14 +715,19 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     size_t spill_ints = 0;
     {
         const size_t sums = 192 * sizeof(double);   // per wave
-        const size_t whole = 4 * kWavesLdsTree * sums + (size_t)stack_depth * 256 * kWavesLdsTree * sizeof(int) +
-                             fl.nodes.size() * LNODE_STRIDE + fl.prims.size() * LPRIM_STRIDE;
+        auto whole_tree = [&](int waves) {
+            return 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + fl.nodes.size() * LNODE_STRIDE + fl.prims.size() * LPRIM_STRIDE;
+        };
+        const char *force_waves = getenv("RTIOW_RENDER_WAVES");   // "3" keeps the 768-thread shape (tests)
+        const int waves_fit = whole_tree(kWavesMax) <= kLdsBudget && !(force_waves && atoi(force_waves) == kWavesMin) ? kWavesMax : kWavesMin;
+        const size_t whole = whole_tree(waves_fit);
         // RTIOW_RENDER_LDS_NODES=k forces the large-tree shape with at most k nodes staged and
         // RTIOW_RENDER_STACK_CAP=c its LDS stack entries, so that small scenes can exercise
         // the staged walk and the spilling stack in tests.
         const char *force_nodes = getenv("RTIOW_RENDER_LDS_NODES"), *force_cap = getenv("RTIOW_RENDER_STACK_CAP");
         if (whole <= kLdsBudget && !force_nodes) {
             s->render_lds_tree = true;
+            s->render_waves = waves_fit;
             s->render_lnodes = (uint32_t)fl.nodes.size();
             s->render_lprims = (uint32_t)fl.prims.size();
             s->render_stack_cap = stack_depth;
@@ -728,14 +735,15 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         } else {
             uint32_t cap = std::min<uint32_t>(stack_depth, kSpillStackCap);
             if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(1, atoi(force_cap)));
-            const size_t base = 4 * kWavesDeviceTree * sums + (size_t)cap * 256 * kWavesDeviceTree * sizeof(int);
+            s->render_waves = kWavesMax;
+            const size_t base = 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
             size_t k = std::min(fl.nodes.size(), (kLdsBudget - base) / LNODE_STRIDE);
             if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
             fl.stage_top_levels(k, items);
             s->render_lnodes = (uint32_t)k;
             s->render_stack_cap = cap;
             s->render_lds_bytes = base + k * LNODE_STRIDE;
-            spill_ints = (size_t)(stack_depth - cap) * s->n_cus * 256 * kWavesDeviceTree;
+            spill_ints = (size_t)(stack_depth - cap) * s->n_cus * 256 * kWavesMax;
         }
     }
     s->n_prims_desc = desc->n_prims;
@@ -781,10 +789,12 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->counter.alloc(4);
     if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
     // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
-    const void *kernels[4] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesLdsTree>),
-                              reinterpret_cast<const void *>(&k_render<double, true, kWavesLdsTree>),
-                              reinterpret_cast<const void *>(&k_render<float, false, kWavesDeviceTree>),
-                              reinterpret_cast<const void *>(&k_render<double, false, kWavesDeviceTree>)};
+    const void *kernels[6] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesMax>),
+                              reinterpret_cast<const void *>(&k_render<double, true, kWavesMax>),
+                              reinterpret_cast<const void *>(&k_render<float, true, kWavesMin>),
+                              reinterpret_cast<const void *>(&k_render<double, true, kWavesMin>),
+                              reinterpret_cast<const void *>(&k_render<float, false, kWavesMax>),
+                              reinterpret_cast<const void *>(&k_render<double, false, kWavesMax>)};
     for (const void *k : kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) {
@@ -802,7 +812,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render kernel: %s, %u nodes and %u spheres in LDS, "
                         "%u stack entries in LDS, %zu B of LDS (budget %zu), %zu B of spill\n",
                 fl.nodes.size(), fl.prims.size(), fl.max_depth, reference_layout ? "reference" : "re-clustered",
-                s->render_lds_tree ? "whole tree in LDS" : "top levels in LDS", s->render_lnodes, s->render_lprims,
+                s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
+                s->render_lnodes, s->render_lprims,
                 s->render_stack_cap, s->render_lds_bytes, kLdsBudget, spill_ints * sizeof(int));
     *out = s;
     return RT_OK;
@@ -944,7 +955,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const uint32_t n_tiles = ((pr->nx + 7) / 8) * ((pr->ny + 7) / 8);
-    const uint32_t waves = 4 * (scene->render_lds_tree ? kWavesLdsTree : kWavesDeviceTree);
+    const uint32_t waves = 4 * (uint32_t)scene->render_waves;
     const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
     const uint32_t spp = pr->sample_end - pr->sample_begin;
     // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
@@ -968,15 +979,16 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     hipLaunchKernelGGL((k_render<T, L, W>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
                        scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST)
+#define RT_LAUNCH_ACC(L, W, S_END, ACCUM, COUNTERS, ORDER, COST)                                                         \
+    do {                                                                                                                  \
+        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, L, W, S_END, ACCUM, COUNTERS, ORDER, COST);                   \
+        else RT_LAUNCH(double, L, W, S_END, ACCUM, COUNTERS, ORDER, COST);                                                \
+    } while (0)
 #define RT_LAUNCH_SHAPE(S_END, ACCUM, COUNTERS, ORDER, COST)                                                              \
     do {                                                                                                                  \
-        if (scene->render_lds_tree) {                                                                                     \
-            if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, true, kWavesLdsTree, S_END, ACCUM, COUNTERS, ORDER, COST); \
-            else RT_LAUNCH(double, true, kWavesLdsTree, S_END, ACCUM, COUNTERS, ORDER, COST);                             \
-        } else {                                                                                                          \
-            if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, false, kWavesDeviceTree, S_END, ACCUM, COUNTERS, ORDER, COST); \
-            else RT_LAUNCH(double, false, kWavesDeviceTree, S_END, ACCUM, COUNTERS, ORDER, COST);                         \
-        }                                                                                                                 \
+        if (!scene->render_lds_tree) RT_LAUNCH_ACC(false, kWavesMax, S_END, ACCUM, COUNTERS, ORDER, COST);                 \
+        else if (scene->render_waves == kWavesMax) RT_LAUNCH_ACC(true, kWavesMax, S_END, ACCUM, COUNTERS, ORDER, COST);    \
+        else RT_LAUNCH_ACC(true, kWavesMin, S_END, ACCUM, COUNTERS, ORDER, COST);                                         \
     } while (0)
     const uint32_t *order = nullptr;
     if (ordered) {
@@ -989,6 +1001,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     }
     RT_LAUNCH_SHAPE(pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
 #undef RT_LAUNCH_SHAPE
+#undef RT_LAUNCH_ACC
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (stats) {

@@ -345,9 +345,14 @@ def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stac
     w_big = rt.World(recipe(scene))
     monkeypatch.delenv("RTIOW_RENDER_LDS_NODES")
     monkeypatch.delenv("RTIOW_RENDER_STACK_CAP")
+    monkeypatch.setenv("RTIOW_RENDER_WAVES", "3")      # the 768-thread shape of trees that only just fit
+    w_768 = rt.World(recipe(scene))
+    monkeypatch.delenv("RTIOW_RENDER_WAVES")
     try:
         fa, sa = w_lds.render(rt.camera(cam15), 72, 36, 0, 5, 21)
         fb, sb = w_big.render(rt.camera(cam15), 72, 36, 0, 5, 21)
+        fc, sc = w_768.render(rt.camera(cam15), 72, 36, 0, 5, 21)
+        assert sc.rays == sa.rays and np.array_equal(fa, fc)
         exp, counters = orc.Scene(recipe(scene)).render(cam15, 72, 36, 0, 5, 21, orc.ORC_RNG_STREAM)
         assert sa.rays == sb.rays == counters.rays
         assert np.array_equal(fa, fb)
@@ -359,6 +364,7 @@ def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stac
     finally:
         w_lds.close()
         w_big.close()
+        w_768.close()
 
 
 def test_cost_ordered_tiles_render_the_same_frame(rt, worlds, monkeypatch):
