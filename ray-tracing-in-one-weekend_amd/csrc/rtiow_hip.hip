@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // the tree fits, the block first copies it into LDS (nodes and spheres, re-strided
 // against bank conflicts) and every traversal step reads LDS instead of the vector cache.
 //
-// A wave owns its tile's 64 x (s_end - s_begin) paths, numbered k = sample * 64 +
+// A wave owns its tile's pixels x (s_end - s_begin) paths, numbered k = sample * pixels +
 // pixel-in-tile; a lane whose path has ended claims the next unclaimed k (lanes that
 // claim together take consecutive numbers), so every lane stays busy until the tile's
 // paths run out, whatever the mix of short sky paths and long glass paths in the tile.
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // keyed by (pixel, sample), so the set of paths -- and every path's arithmetic -- is
 // independent of which lane ran it.
 #ifndef RT_LEAF_QUORUM
-#define RT_LEAF_QUORUM 4
+#define RT_LEAF_QUORUM 16
 #endif
 // Shapes of the kernel.  When nodes, spheres and full-depth stacks fit in LDS every traversal
 // step reads LDS; the block is 1024 threads (4 waves per SIMD, measured 4-5 % faster than 3)
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
                                                        uint32_t n_lprims, uint32_t stack_cap, int *spill,
-                                                       const uint32_t *tile_order, uint32_t *tile_cost) {
+                                                       const uint32_t *tile_order, uint32_t *tile_cost, uint32_t tile_shift) {
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
         __syncthreads();
     }
 
-    const uint32_t tiles_x = (nx + 7) / 8, tiles_y = (ny + 7) / 8, n_tiles = tiles_x * tiles_y;
+    // a tile is 8x8 or 4x4 pixels (tile_shift 3 or 2)
+    const uint32_t tile_side = 1u << tile_shift, tile_px = tile_side * tile_side;
+    const uint32_t tiles_x = (nx + tile_side - 1) >> tile_shift, tiles_y = (ny + tile_side - 1) >> tile_shift, n_tiles = tiles_x * tiles_y;
     unsigned long long nrays = 0;
 
     for (;;) {
@@ -186,8 +188,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= n_tiles) break;
         uint32_t work = 0;   // per lane: traversal iterations and rounds it took part in (see world_closest_voted)
-        const uint32_t tile_x = (tile % tiles_x) * 8, tile_y = (tile / tiles_x) * 8;
-        const uint32_t total = 64u * (s_end - s_begin);
+        const uint32_t tile_x = (tile % tiles_x) << tile_shift, tile_y = (tile / tiles_x) << tile_shift;
+        const uint32_t total = tile_px * (s_end - s_begin);
         uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
         tile_sum[lane] = 0; tile_sum[64 + lane] = 0; tile_sum[128 + lane] = 0;
 
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                 const uint32_t claimed = (uint32_t)__popcll(want);
                 next = (total - next > claimed) ? next + claimed : total;
                 if (!alive && k < total) {
-                    slot = k & 63u;
-                    const uint32_t x = tile_x + (slot & 7u), y = tile_y + (slot >> 3);
+                    slot = k & (tile_px - 1u);
+                    const uint32_t x = tile_x + (slot & (tile_side - 1u)), y = tile_y + (slot >> tile_shift);
                     if (x < nx && y < ny) {
-                        const uint32_t smp = s_begin + (k >> 6);
+                        const uint32_t smp = s_begin + (k >> (2u * tile_shift));
                         g.init(seed, y * nx + x, smp);
                         // the reference's row index runs bottom-up (main.cpp:126)
                         const double ii = (double)x + g.canonical();   // dist{0, 1}: u * 1 + 0 = u
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
             if (lane == 0) tile_cost[tile] = segs;
             continue;
         }
-        const uint32_t x = tile_x + (lane & 7u), y = tile_y + (lane >> 3);
-        if (x < nx && y < ny) {
+        const uint32_t x = tile_x + (lane & (tile_side - 1u)), y = tile_y + (lane >> tile_shift);
+        if (lane < tile_px && x < nx && y < ny) {
             AccT *a = accum + ((size_t)y * nx + x) * 3;
             a[0] += (AccT)tile_sum[lane]; a[1] += (AccT)tile_sum[64 + lane]; a[2] += (AccT)tile_sum[128 + lane];
         }
@@ -954,10 +956,15 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const uint32_t n_tiles = ((pr->nx + 7) / 8) * ((pr->ny + 7) / 8);
+    const uint32_t spp = pr->sample_end - pr->sample_begin;
+    // 8x8-pixel tiles keep all 64 lanes busy from the first sample on; from 64 samples per pixel a
+    // 4x4 tile holds 1024 paths or more, and tiles a quarter the size leave a quarter of the
+    // imbalance at the end of the frame.
+    const uint32_t tile_shift = spp >= 64 ? 2u : 3u, tile_side = 1u << tile_shift;
+    const uint32_t tiles_x = (pr->nx + tile_side - 1) >> tile_shift, tiles_y = (pr->ny + tile_side - 1) >> tile_shift;
+    const uint32_t n_tiles = tiles_x * tiles_y;
     const uint32_t waves = 4 * (uint32_t)scene->render_waves;
     const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
-    const uint32_t spp = pr->sample_end - pr->sample_begin;
     // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
     // the pass traces 1 to 4 samples per pixel without touching the image, under 2 % of the work.
     const bool ordered = spp >= kOrderMinSamples && n_tiles >= 2 * blocks * waves && !getenv("RTIOW_TILE_ORDER_OFF");
@@ -978,7 +985,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
 #define RT_LAUNCH(T, L, W, S_END, ACCUM, COUNTERS, ORDER, COST)                                                           \
     hipLaunchKernelGGL((k_render<T, L, W>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
-                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST)
+                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST, tile_shift)
 #define RT_LAUNCH_ACC(L, W, S_END, ACCUM, COUNTERS, ORDER, COST)                                                         \
     do {                                                                                                                  \
         if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, L, W, S_END, ACCUM, COUNTERS, ORDER, COST);                   \
