@@ -436,7 +436,7 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 //
 // `work` grows by 1 per node iteration and by 3 per leaf iteration this lane took part in: the
 // lane that walked longest has counted what the wave executed, in units of roughly a node step.
-template <int LEAF_QUORUM, bool LDS_TREE>
+template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK>
 __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
                                                     double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work) {
     constexpr bool SPILL = !LDS_TREE;
@@ -450,13 +450,13 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
             const int n_node = __popcll(__ballot(at_node));
             const int n_leaf = __popcll(__ballot(!at_node));
             if (n_leaf >= LEAF_QUORUM || n_node == 0) {
-                work += 3;
+                if (COUNT_WORK) work += 3;
                 if (!at_node) {
                     if (LDS_TREE) leaf_step_lds<SPILL>(tree.lprims, r, tmin, closest, st, tv);
                     else leaf_step<SPILL>(tree.prims, r, tmin, closest, st, tv);
                 }
             } else {
-                work += 1;
+                if (COUNT_WORK) work += 1;
                 if (at_node) {
                     if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin, closest, st, tv);
                     else node_step<SPILL>(tree.nodes, r, tmin, closest, st, tv);

@@ -143,7 +143,9 @@ constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 constexpr uint32_t kOrderMinSamples = 32;               // frames at least this deep get their tiles ordered by cost
 
-template <class AccT, bool LDS_TREE, int WAVES>
+// COSTING: the pass that ranks the tiles -- the same walk over a few samples, but instead of
+// adding to the image each tile records how much work it was (tile_cost).
+template <class AccT, bool LDS_TREE, int WAVES, bool COSTING>
 __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
@@ -234,8 +236,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                 double t;
                 int prim;
                 ++nrays;
-                work += 8;   // claiming, set-up and shading of one segment, in node-step units
-                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work)) {
+                if (COSTING) work += 8;   // claiming, set-up and shading of one segment, in node-step units
+                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE, COSTING>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work)) {
                     v3 p, nn, att;
                     Ray nextray;
                     hit_point(sc, prim, ctx, t, p, nn);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                 }
             }
         }
-        if (tile_cost) {
+        if (COSTING) {
             // costing pass: the image is not touched; the tile's cost is the work its busiest lane
             // counted (a count, not a duration: durations depend on what else the CU is running)
             uint32_t segs = work;
@@ -791,12 +793,15 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->counter.alloc(4);
     if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
     // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
-    const void *kernels[6] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesMax>),
-                              reinterpret_cast<const void *>(&k_render<double, true, kWavesMax>),
-                              reinterpret_cast<const void *>(&k_render<float, true, kWavesMin>),
-                              reinterpret_cast<const void *>(&k_render<double, true, kWavesMin>),
-                              reinterpret_cast<const void *>(&k_render<float, false, kWavesMax>),
-                              reinterpret_cast<const void *>(&k_render<double, false, kWavesMax>)};
+    const void *kernels[9] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, false>),
+                              reinterpret_cast<const void *>(&k_render<double, true, kWavesMax, false>),
+                              reinterpret_cast<const void *>(&k_render<float, true, kWavesMin, false>),
+                              reinterpret_cast<const void *>(&k_render<double, true, kWavesMin, false>),
+                              reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, false>),
+                              reinterpret_cast<const void *>(&k_render<double, false, kWavesMax, false>),
+                              reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, true>),
+                              reinterpret_cast<const void *>(&k_render<float, true, kWavesMin, true>),
+                              reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, true>)};
     for (const void *k : kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) {
@@ -960,7 +965,9 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     // 8x8-pixel tiles keep all 64 lanes busy from the first sample on; from 64 samples per pixel a
     // 4x4 tile holds 1024 paths or more, and tiles a quarter the size leave a quarter of the
     // imbalance at the end of the frame.
-    const uint32_t tile_shift = spp >= 64 ? 2u : 3u, tile_side = 1u << tile_shift;
+    uint32_t tile_shift = spp >= 64 ? 2u : 3u;
+    if (const char *e = getenv("RTIOW_TILE_SHIFT")) tile_shift = std::min(3u, std::max(1u, (uint32_t)atoi(e)));   // 1: 2x2 ... 3: 8x8 (experiments)
+    const uint32_t tile_side = 1u << tile_shift;
     const uint32_t tiles_x = (pr->nx + tile_side - 1) >> tile_shift, tiles_y = (pr->ny + tile_side - 1) >> tile_shift;
     const uint32_t n_tiles = tiles_x * tiles_y;
     const uint32_t waves = 4 * (uint32_t)scene->render_waves;
@@ -982,33 +989,28 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     }
     dim3 grid(blocks), block(64 * waves);
     DCamera cam = to_dcamera(camera);
-#define RT_LAUNCH(T, L, W, S_END, ACCUM, COUNTERS, ORDER, COST)                                                           \
-    hipLaunchKernelGGL((k_render<T, L, W>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
+#define RT_LAUNCH(T, L, W, C, S_END, ACCUM, COUNTERS, ORDER, COST)                                                           \
+    hipLaunchKernelGGL((k_render<T, L, W, C>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
                        scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST, tile_shift)
-#define RT_LAUNCH_ACC(L, W, S_END, ACCUM, COUNTERS, ORDER, COST)                                                         \
+#define RT_LAUNCH_SHAPE(T, C, S_END, ACCUM, COUNTERS, ORDER, COST)                                                        \
     do {                                                                                                                  \
-        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH(float, L, W, S_END, ACCUM, COUNTERS, ORDER, COST);                   \
-        else RT_LAUNCH(double, L, W, S_END, ACCUM, COUNTERS, ORDER, COST);                                                \
-    } while (0)
-#define RT_LAUNCH_SHAPE(S_END, ACCUM, COUNTERS, ORDER, COST)                                                              \
-    do {                                                                                                                  \
-        if (!scene->render_lds_tree) RT_LAUNCH_ACC(false, kWavesMax, S_END, ACCUM, COUNTERS, ORDER, COST);                 \
-        else if (scene->render_waves == kWavesMax) RT_LAUNCH_ACC(true, kWavesMax, S_END, ACCUM, COUNTERS, ORDER, COST);    \
-        else RT_LAUNCH_ACC(true, kWavesMin, S_END, ACCUM, COUNTERS, ORDER, COST);                                         \
+        if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST);               \
+        else if (scene->render_waves == kWavesMax) RT_LAUNCH(T, true, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST);  \
+        else RT_LAUNCH(T, true, kWavesMin, C, S_END, ACCUM, COUNTERS, ORDER, COST);                                       \
     } while (0)
     const uint32_t *order = nullptr;
     if (ordered) {
         uint32_t *cost = scene->tiles.p, *sorted = scene->tiles.p + n_tiles;
         uint32_t probe = std::min(4u, std::max(1u, spp / 64u));   // measured: 1 sample ranks noisily, more than 4 costs more than it saves
         if (const char *e = getenv("RTIOW_TILE_PROBE")) probe = std::min<uint32_t>(spp, (uint32_t)std::max(1, atoi(e)));
-        RT_LAUNCH_SHAPE(pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost);
+        RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost);
         hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, n_tiles, sorted);
         order = sorted;
     }
-    RT_LAUNCH_SHAPE(pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
+    if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
+    else RT_LAUNCH_SHAPE(double, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
 #undef RT_LAUNCH_SHAPE
-#undef RT_LAUNCH_ACC
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (stats) {

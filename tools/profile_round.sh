@@ -2,7 +2,7 @@
 # Produces the profile artefacts of a round under gpurun_out/ (copy the summaries to profiles/):
 #   1. rocprofv3 --kernel-trace --stats of the default bench run (the judged configuration)
 #   2. FETCH_SIZE / WRITE_SIZE passes of the same configuration (HBM traffic of one k_render launch)
-#   3. SQ / TCC / LDS counter passes at 32 spp (tools/pmc_profile.sh)
+#   3. SQ / TCC / LDS counter passes at 64 spp (tools/pmc_profile.sh)
 # usage: tools/profile_round.sh TAG      (run from the repository root, on the GPU box)
 set -u
 TAG=$1
@@ -15,7 +15,7 @@ grep '"metric"' "$R/$OUT/bench.log" > "$R/$OUT/bench.json"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$R/$OUT" -o full_$c -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$R/$OUT/full_$c.log" 2>&1 || { echo "pass $c failed"; exit 1; }
 done
-cd "$R" && tools/pmc_profile.sh "$OUT/pmc32" --spp 32 && python3 tools/pmc_summary.py "$OUT/pmc32" > "$OUT/pmc32_summary.txt"
+cd "$R" && tools/pmc_profile.sh "$OUT/pmc64" --spp 64 && python3 tools/pmc_summary.py "$OUT/pmc64" > "$OUT/pmc64_summary.txt"
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
 out = sys.argv[1]
