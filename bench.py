@@ -240,7 +240,7 @@ def main():
                        "nx": args.nx, "ny": args.ny, "spp_per_gpu": args.spp, "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
             "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per step: costing pass + main launch (PMC, profiles/traffic.json)",
                          "algorithmic_bytes_per_launch": launch_paths * bytes_per_path, "kernel": "k_render<float, lds_tree, 4 waves> (+ its costing pass and tile sort)", "kernel_ms": k_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms],
                          "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,
                          "valu_f64": {"achieved_tflops": launch_paths * flops_per_path / k_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
