@@ -293,8 +293,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float *accum, size_t n
 // sample range, and tiles differ in cost by an order of magnitude (sky against glass), so
 // handing them out in image order leaves a few waves finishing the last, dear tiles while
 // the rest of the chip idles; longest-first keeps the end of the frame to the cheap ones.
+//
+// Costs are measured on 8x8-pixel tiles (a few samples of a smaller tile would not fill a
+// wave); when the frame is rendered in smaller tiles each inherits the cost of the 8x8 tile
+// it lies in (`sub` = log2 of the ratio of the sides).
 constexpr int kOrderBlock = 1024;
-__global__ __launch_bounds__(kOrderBlock) void k_order_tiles(const uint32_t *cost, uint32_t n, uint32_t *order) {
+__global__ __launch_bounds__(kOrderBlock) void k_order_tiles(const uint32_t *cost, uint32_t cost_tiles_x, uint32_t n_cost,
+                                                            uint32_t tiles_x, uint32_t n, uint32_t sub, uint32_t *order) {
     __shared__ uint32_t hist[kOrderBlock];
     __shared__ uint32_t cmax;
     const uint32_t tid = threadIdx.x;
@@ -302,19 +307,22 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_tiles(const uint32_t *cos
     if (tid == 0) cmax = 1;
     __syncthreads();
     uint32_t m = 1;
-    for (uint32_t i = tid; i < n; i += kOrderBlock) m = cost[i] > m ? cost[i] : m;
+    for (uint32_t i = tid; i < n_cost; i += kOrderBlock) m = cost[i] > m ? cost[i] : m;
     atomicMax(&cmax, m);
     __syncthreads();
     const unsigned long long top = cmax;
-    for (uint32_t i = tid; i < n; i += kOrderBlock) atomicAdd(&hist[(uint32_t)((unsigned long long)cost[i] * (kOrderBlock - 1) / top)], 1u);
+    auto klass = [&](uint32_t i) {
+        const uint32_t x = i % tiles_x, y = i / tiles_x;
+        return (uint32_t)((unsigned long long)cost[(y >> sub) * cost_tiles_x + (x >> sub)] * (kOrderBlock - 1) / top);
+    };
+    for (uint32_t i = tid; i < n; i += kOrderBlock) atomicAdd(&hist[klass(i)], 1u);
     __syncthreads();
     if (tid == 0) {   // start of each class in the output, dearest class first
         uint32_t at = 0;
         for (int b = kOrderBlock - 1; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = at; at += c; }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += kOrderBlock)
-        order[atomicAdd(&hist[(uint32_t)((unsigned long long)cost[i] * (kOrderBlock - 1) / top)], 1u)] = i;
+    for (uint32_t i = tid; i < n; i += kOrderBlock) order[atomicAdd(&hist[klass(i)], 1u)] = i;
 }
 
 }  // namespace
@@ -975,7 +983,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
     // the pass traces 1 to 4 samples per pixel without touching the image, under 2 % of the work.
     const bool ordered = spp >= kOrderMinSamples && n_tiles >= 2 * blocks * waves && !getenv("RTIOW_TILE_ORDER_OFF");
-    if (ordered && scene->tiles_capacity < 2 * (size_t)n_tiles) {
+    if (ordered && scene->tiles_capacity < 2 * (size_t)n_tiles) {   // costs of the 8x8 tiles (at most n_tiles of them), then the order
         if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
         HIP_TRY(scene->tiles.alloc(2 * (size_t)n_tiles));
         scene->tiles_capacity = 2 * (size_t)n_tiles;
@@ -989,27 +997,28 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     }
     dim3 grid(blocks), block(64 * waves);
     DCamera cam = to_dcamera(camera);
-#define RT_LAUNCH(T, L, W, C, S_END, ACCUM, COUNTERS, ORDER, COST)                                                           \
+#define RT_LAUNCH(T, L, W, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                           \
     hipLaunchKernelGGL((k_render<T, L, W, C>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
-                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST, tile_shift)
-#define RT_LAUNCH_SHAPE(T, C, S_END, ACCUM, COUNTERS, ORDER, COST)                                                        \
+                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST, SHIFT)
+#define RT_LAUNCH_SHAPE(T, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
     do {                                                                                                                  \
-        if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST);               \
-        else if (scene->render_waves == kWavesMax) RT_LAUNCH(T, true, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST);  \
-        else RT_LAUNCH(T, true, kWavesMin, C, S_END, ACCUM, COUNTERS, ORDER, COST);                                       \
+        if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \
+        else if (scene->render_waves == kWavesMax) RT_LAUNCH(T, true, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);  \
+        else RT_LAUNCH(T, true, kWavesMin, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                                       \
     } while (0)
     const uint32_t *order = nullptr;
     if (ordered) {
-        uint32_t *cost = scene->tiles.p, *sorted = scene->tiles.p + n_tiles;
+        const uint32_t cost_tiles_x = (pr->nx + 7) / 8, n_cost = cost_tiles_x * ((pr->ny + 7) / 8);
+        uint32_t *cost = scene->tiles.p, *sorted = scene->tiles.p + n_cost;
         uint32_t probe = std::min(4u, std::max(1u, spp / 64u));   // measured: 1 sample ranks noisily, more than 4 costs more than it saves
         if (const char *e = getenv("RTIOW_TILE_PROBE")) probe = std::min<uint32_t>(spp, (uint32_t)std::max(1, atoi(e)));
-        RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost);
-        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, n_tiles, sorted);
+        RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost, 3u);
+        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, tiles_x, n_tiles, 3u - tile_shift, sorted);
         order = sorted;
     }
-    if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
-    else RT_LAUNCH_SHAPE(double, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr);
+    if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr, tile_shift);
+    else RT_LAUNCH_SHAPE(double, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr, tile_shift);
 #undef RT_LAUNCH_SHAPE
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
