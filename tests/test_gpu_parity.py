@@ -269,6 +269,38 @@ def test_full_size_frame_properties(rt, worlds):
     assert np.sqrt(np.mean((res - ref_c) ** 2)) < 0.06
 
 
+def test_deep_frames_at_full_size(rt, worlds, monkeypatch):
+    # 64 samples per pixel at 1920x1080: the path the benchmark takes (costing pass, tiles dearest
+    # first, 4x4-pixel tiles).  Size-independent properties: run-to-run determinism, additivity
+    # over sample ranges (the halves are rendered in 8x8 tiles, the whole in 4x4: same paths,
+    # sums in another order), and the same frame from other tile sizes and from image order.
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = 1920 / 1080
+    cam = rt.camera(cam15)
+    w = worlds("book2")
+    whole, s = w.render(cam, 1920, 1080, 0, 64, 3, rt.RT_ACCUM_F64)
+    again, s2 = w.render(cam, 1920, 1080, 0, 64, 3, rt.RT_ACCUM_F64)
+    assert np.array_equal(whole, again) and s.rays == s2.rays
+    a, sa = w.render(cam, 1920, 1080, 0, 32, 3, rt.RT_ACCUM_F64)
+    b, sb = w.render(cam, 1920, 1080, 32, 64, 3, rt.RT_ACCUM_F64)
+    assert sa.rays + sb.rays == s.rays
+    np.testing.assert_allclose(a + b, whole, rtol=1e-12, atol=1e-12)
+    # a ragged size, every tile size, with and without ordering
+    cam15[10] = 1001 / 701
+    cam = rt.camera(cam15)
+    base, sbase = w.render(cam, 1001, 701, 5, 69, 3, rt.RT_ACCUM_F64)
+    for shift in ("1", "2", "3"):
+        monkeypatch.setenv("RTIOW_TILE_SHIFT", shift)
+        other, so = w.render(cam, 1001, 701, 5, 69, 3, rt.RT_ACCUM_F64)
+        monkeypatch.setenv("RTIOW_TILE_ORDER_OFF", "1")
+        plain, sp = w.render(cam, 1001, 701, 5, 69, 3, rt.RT_ACCUM_F64)
+        monkeypatch.delenv("RTIOW_TILE_ORDER_OFF")
+        monkeypatch.delenv("RTIOW_TILE_SHIFT")
+        assert so.rays == sbase.rays == sp.rays
+        assert np.array_equal(other, plain)
+        np.testing.assert_allclose(other, base, rtol=1e-12, atol=1e-12)
+
+
 def test_resolve(rt):
     import torch
     sums = torch.rand(4096 * 3, device="cuda") * 8
