@@ -970,10 +970,10 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     hipStream_t stream = (hipStream_t)stream_v;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const uint32_t spp = pr->sample_end - pr->sample_begin;
-    // 8x8-pixel tiles keep all 64 lanes busy from the first sample on; from 64 samples per pixel a
-    // 4x4 tile holds 1024 paths or more, and tiles a quarter the size leave a quarter of the
-    // imbalance at the end of the frame.
-    uint32_t tile_shift = spp >= 64 ? 2u : 3u;
+    // 8x8-pixel tiles fill the 64 lanes with a single sample per pixel; from 4 samples per pixel a
+    // 4x4 tile does, and tiles a quarter the size leave a quarter of the imbalance at the end of
+    // the frame (measured faster from 8 to 1024 samples, within 2 % at 32).
+    uint32_t tile_shift = spp >= 4 ? 2u : 3u;
     if (const char *e = getenv("RTIOW_TILE_SHIFT")) tile_shift = std::min(3u, std::max(1u, (uint32_t)atoi(e)));   // 1: 2x2 ... 3: 8x8 (experiments)
     const uint32_t tile_side = 1u << tile_shift;
     const uint32_t tiles_x = (pr->nx + tile_side - 1) >> tile_shift, tiles_y = (pr->ny + tile_side - 1) >> tile_shift;
