@@ -15,19 +15,27 @@
 namespace rtd {
 
 // ---------------------------------------------------------------- scene layout ----
-// A node of the device tree is a reference node whose children are both nodes; it holds
-// the boxes of BOTH children, so a single fetch decides both descents.  A reference node
-// whose children are primitives (bvh_node.cpp:31-37: one object twice, or two objects)
-// becomes a "leaf": its box sits in its parent's child slot like any other, and visiting
-// it means testing its one or two spheres, which are adjacent in the primitive table.
+// Which leaves of the reference's tree a ray reaches depends only on the leaves' own boxes
+// (see the flattener in rtiow_hip.hip), so the inner boxes only have to CONTAIN the leaf
+// boxes below them.  A node of the device tree therefore holds the boxes of both children
+// in single precision, rounded outward, and its slab test is a conservative one (node_test):
+// it may let a ray into a subtree the reference would have skipped, never the reverse.  What
+// the reference computes -- the double-precision test of aabb.cpp:8-57 -- is done on the box of
+// each leaf (DLeaf) before its spheres are tried: the walk reaches a superset of the
+// reference's leaves and that test removes the excess.
+//
+// A leaf is a reference node whose children are primitives (bvh_node.cpp:31-37: one object
+// twice, or two objects); its one or two spheres are entries 2*leaf and 2*leaf+1 of the
+// primitive table.
 struct __attribute__((aligned(16))) DNode {
-    double bx[2][6];   // per child: min x, max x, min y, max y, min z, max z
+    float bx[2][6];    // per child: min x, max x, min y, max y, min z, max z (rounded outward)
     int32_t child[2];  // >= 0 node index, < 0 leaf reference (see leaf_ref)
     uint32_t flags;    // NF_SAFE0 | NF_SAFE1
-    uint32_t pad0;
-    double pad1[2];
+    uint32_t pad;
 };
-static_assert(sizeof(DNode) == 128, "DNode is two 64-byte lines");
+static_assert(sizeof(DNode) == 64, "DNode is one 64-byte line");
+
+struct DLeaf { double box[6]; };   // the reference's box of the leaf: min x, max x, min y, max y, min z, max z
 
 // Every primitive under a SAFE child stays inside the child's box (static spheres), so
 // the descent may be skipped once the box starts beyond the best hit.  A moving sphere
@@ -35,12 +43,12 @@ static_assert(sizeof(DNode) == 128, "DNode is two 64-byte lines");
 // always visited, as the reference visits them.
 enum : uint32_t { NF_SAFE0 = 1u, NF_SAFE1 = 2u };
 
-// leaf reference: bit 31 set; bits 0-27 first primitive (device order); bit 28: a second
-// primitive follows; bits 29, 30: first / second primitive is a moving sphere
+// leaf reference: bit 31 set; bits 0-26 leaf number; bit 27: all its spheres are static; bit 28:
+// it has a second sphere; bits 29, 30: first / second sphere is a moving sphere
 constexpr int32_t LEAF_BIT = (int32_t)0x80000000u;
-constexpr int32_t LEAF_TWO = 1 << 28, LEAF_MOVING0 = 1 << 29, LEAF_MOVING1 = 1 << 30;
-constexpr int32_t LEAF_INDEX_MASK = 0x0FFFFFFF;
-constexpr int32_t REF_NONE = (int32_t)0x8FFFFFFFu;   // a leaf index no scene can reach
+constexpr int32_t LEAF_SAFE = 1 << 27, LEAF_TWO = 1 << 28, LEAF_MOVING0 = 1 << 29, LEAF_MOVING1 = 1 << 30;
+constexpr int32_t LEAF_INDEX_MASK = 0x07FFFFFF;
+constexpr int32_t REF_NONE = (int32_t)0x87FFFFFFu;   // a leaf number no scene can reach
 
 enum : uint32_t { PK_STATIC = 0, PK_MOVING = 1, PK_MOVING_UNIT = 2 };
 
@@ -60,7 +68,8 @@ struct DTex { uint32_t kind; uint32_t even, odd; uint32_t pad; double c[3]; };
 
 struct DScene {
     const DNode *nodes;
-    const DPrim *prims;
+    const DLeaf *leaves;
+    const DPrim *prims;       // 2 per leaf
     const DItem *items;
     const DMat *mats;
     const DTex *texs;
@@ -99,7 +108,20 @@ struct RayCtx {
     // the plane the ray meets first inside a (min, max) pair: 0 or 8.
     uint32_t nx8, ny8, nz8;
     double a;            // d.d (sphere.cpp:14)
+    // single-precision constants of the conservative node test: t = plane * i + c with
+    // i = 1/d and c = -o/d per axis, and the widening K * max|c| (see node_test)
+    float ixf, iyf, izf, cxf, cyf, czf, widen;
 };
+
+// The conservative test computes t = fma(plane, i, c) in single precision for a plane that was
+// rounded outward.  Against the exact (plane - o) / d: i and c carry a relative rounding error
+// of 2^-24 each and the fma another, so |t - exact| <= 2^-22 (|t| + |c|); the test widens by
+// K (|t| + max|c|) with K = 2^-21, twice that.
+constexpr float kWidenK = 0x1p-21f;
+// a bound rounded away from the interval: x lowered (raised) by at least its conversion error
+__device__ __forceinline__ float below(double x) { const float f = (float)x; return f - __builtin_fabsf(f) * 0x1p-22f; }
+__device__ __forceinline__ float above(double x) { const float f = (float)x; return f + __builtin_fabsf(f) * 0x1p-22f; }
+
 
 __device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
     RayCtx c;
@@ -107,6 +129,12 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
     c.ix = 1.0 / r.d.x; c.iy = 1.0 / r.d.y; c.iz = 1.0 / r.d.z;
     c.nx8 = c.ix < 0 ? 8u : 0u; c.ny8 = c.iy < 0 ? 8u : 0u; c.nz8 = c.iz < 0 ? 8u : 0u;
     c.a = vdot(r.d, r.d);
+    c.ixf = (float)c.ix; c.iyf = (float)c.iy; c.izf = (float)c.iz;
+    c.cxf = (float)-(r.o.x * c.ix); c.cyf = (float)-(r.o.y * c.iy); c.czf = (float)-(r.o.z * c.iz);
+    // a zero, huge or NaN direction component makes an infinite or NaN constant; the test then
+    // yields NaN bounds, and NaN bounds pass: such rays simply visit more of the tree
+    c.widen = kWidenK * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c.cxf), __builtin_fabsf(c.cyf)), __builtin_fabsf(c.czf));
+    if (!(c.cxf == c.cxf && c.cyf == c.cyf && c.czf == c.czf)) c.widen = __builtin_nanf("");
     return c;
 }
 
@@ -254,6 +282,7 @@ struct Trav {
     int32_t sp;      // stack entries in use
     double bt;       // best hit of the item being walked
     int32_t bp;      // its primitive (device order), -1 = none
+    float bt_above;  // bt rounded up, for the conservative node test
 };
 
 // A lane's traversal stack.  Entry k lives in LDS at lds[k * stride] (the block's lanes are
@@ -283,7 +312,7 @@ template <bool SPILL> __device__ __forceinline__ int32_t trav_pop(Trav &tv, cons
 }
 
 template <bool SPILL>
-__device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, bool h1, double e0, double e1, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, bool h1, float e0, float e1, const LaneStack &st, Trav &tv) {
     const bool near0 = e0 <= e1;
     if (h0 && h1) {
         stack_put<SPILL>(st, tv.sp, near0 ? c1 : c0);
@@ -296,94 +325,142 @@ __device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, boo
     }
 }
 
-// One node: test both child boxes, continue with the nearer, push the farther.
+// The conservative slab test of one child box.  n* are the planes the ray meets first on each
+// axis, f* the ones it meets last (outward-rounded single precision).  Returns false only when
+// the exact test of aabb.cpp:8-57 on the box inside would fail: the entry bound is lowered and the
+// exit bound raised by the rounding error bound of make_ctx's constants, a NaN plane (0 * inf)
+// drops out of max3/min3 as it leaves the reference's bounds unchanged, and NaN bounds pass.
+// `entry` is a lower bound of the exact entry distance.
+__device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy, float nz, float fz, const RayCtx &r,
+                                          float tmin_below, float tmax_above, float &entry) {
+    const float tnx = __builtin_fmaf(nx, r.ixf, r.cxf), tfx = __builtin_fmaf(fx, r.ixf, r.cxf);
+    const float tny = __builtin_fmaf(ny, r.iyf, r.cyf), tfy = __builtin_fmaf(fy, r.iyf, r.cyf);
+    const float tnz = __builtin_fmaf(nz, r.izf, r.czf), tfz = __builtin_fmaf(fz, r.izf, r.czf);
+    const float e = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float x = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+    const float e_lo = __builtin_fmaf(__builtin_fabsf(e), -kWidenK, e) - r.widen;
+    const float x_hi = __builtin_fmaf(__builtin_fabsf(x), kWidenK, x) + r.widen;
+    entry = e_lo;
+    return !(__builtin_fminf(x_hi, tmax_above) < __builtin_fmaxf(e_lo, tmin_below));
+}
+
+// One node read from device memory: test both child boxes, continue with the nearer, push the
+// farther.  A SAFE child is also skipped when it starts beyond the best hit so far.
 template <bool SPILL>
-__device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
     const DNode *nd = nodes + tv.cur;
     const uint32_t flags = nd->flags;
     const int32_t c0 = nd->child[0], c1 = nd->child[1];
-    double b0[6], b1[6];
+    float b[2][6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { b0[k] = nd->bx[0][k]; b1[k] = nd->bx[1][k]; }
-    double e0, e1;
+    for (int k = 0; k < 6; ++k) { b[0][k] = nd->bx[0][k]; b[1][k] = nd->bx[1][k]; }
+    float e[2];
+    bool h[2];
     const bool none = tv.bp < 0;
-    const bool h0 = box_test(b0, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || none || e0 <= tv.bt);
-    const bool h1 = box_test(b1, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || none || e1 <= tv.bt);
-    node_decide<SPILL>(c0, c1, h0, h1, e0, e1, st, tv);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        h[c] = node_test(r.nx8 ? b[c][1] : b[c][0], r.nx8 ? b[c][0] : b[c][1], r.ny8 ? b[c][3] : b[c][2], r.ny8 ? b[c][2] : b[c][3],
+                         r.nz8 ? b[c][5] : b[c][4], r.nz8 ? b[c][4] : b[c][5], r, tmin_below, tmax_above, e[c]);
+        h[c] = h[c] && (!(flags & (c ? NF_SAFE1 : NF_SAFE0)) || none || !(e[c] > tv.bt_above));
+    }
+    node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
 }
 
 // Records of the LDS copy of the tree.  The strides are chosen so that lanes reading the
-// same field of different records spread over the banks: 120 B = 30 dwords and
-// 88 B = 22 dwords share only a factor 2 with the 64 banks, which a 64-bit read covers.
-constexpr uint32_t LNODE_STRIDE = 120;   // bx[2][6] | child[2] | flags | pad
-constexpr uint32_t LPRIM_STRIDE = 88;    // c0[3] r dc[3] t0 t1 | mat kind orig pad
+// same field of different records spread over the 64 banks: 17 dwords for the 32-bit reads
+// of a node, 58 dwords (a factor 2, which a 64-bit read covers) for a leaf.
+constexpr uint32_t LNODE_STRIDE = 68;    // bx[2][6] floats | child[2] | flags
+constexpr uint32_t LPRIM_BYTES = 88;     // c0[3] r dc[3] t0 t1 | mat kind orig pad
+constexpr uint32_t LLEAF_STRIDE = 232;   // box[6] doubles | sphere | sphere | pad
 
 // Where a walk finds the tree.  The block's LDS holds the first n_lnodes nodes (all of them
 // when the tree fits, else its top levels: nodes are numbered breadth-first there) and,
-// when lprims is set, every sphere; the rest is read from device memory.
+// when lleaves is set, every leaf; the rest is read from device memory.
 struct TreeView {
     const DNode *nodes;     // device memory
+    const DLeaf *leaves;
     const DPrim *prims;
     const char *lnodes;     // LDS copies
-    const char *lprims;
+    const char *lleaves;
     int32_t n_lnodes;
 };
 
-// node_step on the LDS copy
+// node_step on the LDS copy; the planes are read in the order the ray meets them (the swap of
+// aabb.cpp:16-18 becomes a choice of address, free when every lane reads its own node anyway)
 template <bool SPILL>
-__device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
     const char *nd = lnodes + (uint32_t)tv.cur * LNODE_STRIDE;
-    const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 96), c1 = *reinterpret_cast<const int32_t *>(nd + 100);
-    const uint32_t flags = *reinterpret_cast<const uint32_t *>(nd + 104);
-    double e0, e1;
+    const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 48), c1 = *reinterpret_cast<const int32_t *>(nd + 52);
+    const uint32_t flags = *reinterpret_cast<const uint32_t *>(nd + 56);
+    const uint32_t ox = r.nx8 >> 1, oy = r.ny8 >> 1, oz = r.nz8 >> 1;   // 0 or 4: byte offset of the nearer plane in a pair
+    float e[2];
+    bool h[2];
     const bool none = tv.bp < 0;
-    const bool h0 = box_test_ordered(nd, r, tmin, tmax, e0) && (!(flags & NF_SAFE0) || none || e0 <= tv.bt);
-    const bool h1 = box_test_ordered(nd + 48, r, tmin, tmax, e1) && (!(flags & NF_SAFE1) || none || e1 <= tv.bt);
-    node_decide<SPILL>(c0, c1, h0, h1, e0, e1, st, tv);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const char *b = nd + 24 * c;
+        h[c] = node_test(*reinterpret_cast<const float *>(b + ox), *reinterpret_cast<const float *>(b + (ox ^ 4u)),
+                         *reinterpret_cast<const float *>(b + 8 + oy), *reinterpret_cast<const float *>(b + 8 + (oy ^ 4u)),
+                         *reinterpret_cast<const float *>(b + 16 + oz), *reinterpret_cast<const float *>(b + 16 + (oz ^ 4u)),
+                         r, tmin_below, tmax_above, e[c]);
+        h[c] = h[c] && (!(flags & (c ? NF_SAFE1 : NF_SAFE0)) || none || !(e[c] > tv.bt_above));
+    }
+    node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
+}
+
+__device__ __forceinline__ void take_if_closer(double t, int32_t prim, Trav &tv) {
+    if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; tv.bt_above = above(t); }
 }
 
 __device__ __forceinline__ void leaf_candidate(const DPrim *prims, int32_t prim, bool moving, const RayCtx &r,
                                                double tmin, double tmax, Trav &tv) {
     const DPrim *p = prims + prim;
     double t;
-    if (sphere_root(prim_centre(p, moving, r.time), p->r, r, tmin, tmax, t)) {
-        if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; }
-    }
+    if (sphere_root(prim_centre(p, moving, r.time), p->r, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
 }
 
-__device__ __forceinline__ void leaf_candidate_lds(const char *lprims, int32_t prim, bool moving, const RayCtx &r,
+__device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim, bool moving, const RayCtx &r,
                                                    double tmin, double tmax, Trav &tv) {
-    const double *p = reinterpret_cast<const double *>(lprims + (uint32_t)prim * LPRIM_STRIDE);
+    const double *p = reinterpret_cast<const double *>(rec);
     v3 c = mk(p[0], p[1], p[2]);
     const double radius = p[3];
     if (moving) {
-        const uint32_t kind = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p) + 76);
+        const uint32_t kind = *reinterpret_cast<const uint32_t *>(rec + 76);
         const double s = (kind == PK_MOVING_UNIT) ? r.time : (r.time - p[7]) / (p[8] - p[7]);
         c = vadd(c, vmul(mk(p[4], p[5], p[6]), s));
     }
     double t;
-    if (sphere_root(c, radius, r, tmin, tmax, t)) {
-        if (tv.bp < 0 || t < tv.bt || (t == tv.bt && prim > tv.bp)) { tv.bt = t; tv.bp = prim; }
-    }
+    if (sphere_root(c, radius, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
 }
 
+// One leaf.  First the reference's own test of the leaf's box (aabb.cpp:8-57, in double, with the
+// interval the reference would pass down: bvh_node.cpp:53) -- the walk above it was only
+// conservative; a leaf of static spheres is also skipped when its box starts beyond the best hit.
+// Then its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the next stack entry.
 template <bool SPILL>
-__device__ __forceinline__ void leaf_step_lds(const char *lprims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
     const int32_t ref = tv.cur;
-    const int32_t first = ref & LEAF_INDEX_MASK;
-    leaf_candidate_lds(lprims, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
-    if (ref & LEAF_TWO) leaf_candidate_lds(lprims, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    const int32_t leaf = ref & LEAF_INDEX_MASK;
+    const char *rec = lleaves + (uint32_t)leaf * LLEAF_STRIDE;
+    double entry;
+    if (box_test_ordered(rec, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt)) {
+        leaf_candidate_lds(rec + 48, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
+        if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    }
     tv.cur = trav_pop<SPILL>(tv, st);
 }
 
-// One leaf: its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the
-// next stack entry.
 template <bool SPILL>
-__device__ __forceinline__ void leaf_step(const DPrim *prims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
     const int32_t ref = tv.cur;
-    const int32_t first = ref & LEAF_INDEX_MASK;
-    leaf_candidate(prims, first, ref & LEAF_MOVING0, r, tmin, tmax, tv);
-    if (ref & LEAF_TWO) leaf_candidate(prims, first + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    const int32_t leaf = ref & LEAF_INDEX_MASK;
+    double bx[6], entry;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bx[k] = leaves[leaf].box[k];
+    if (box_test(bx, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt)) {
+        leaf_candidate(prims, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
+        if (ref & LEAF_TWO) leaf_candidate(prims, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+    }
     tv.cur = trav_pop<SPILL>(tv, st);
 }
 
@@ -391,7 +468,7 @@ __device__ __forceinline__ void leaf_step(const DPrim *prims, const RayCtx &r, d
 // (bvh_node.cpp:53).  Returns false when the item cannot be hit.
 __device__ __forceinline__ bool item_begin(const DScene &sc, uint32_t item, const RayCtx &r, double tmin, double tmax, Trav &tv) {
     const DItem *it = sc.items + item;
-    tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.cur = REF_NONE;
+    tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.bt_above = 0; tv.cur = REF_NONE;
     if (it->has_box) {
         double bx[6], entry;
 #pragma unroll
@@ -408,14 +485,16 @@ __device__ __forceinline__ bool item_begin(const DScene &sc, uint32_t item, cons
 __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r, double tmin, double tmax,
                                               int *stack, int stride, double &t_out, int &prim_out) {
     const LaneStack st = {stack, stride, 0, nullptr, 0};   // whole stack in LDS
+    const float tmin_below = below(tmin);
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
         Trav tv;
         if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
+        const float tmax_above = above(closest);
         while (tv.cur != REF_NONE) {
-            if (tv.cur >= 0) node_step<false>(sc.nodes, r, tmin, closest, st, tv);
-            else leaf_step<false>(sc.prims, r, tmin, closest, st, tv);
+            if (tv.cur >= 0) node_step<false>(sc.nodes, r, tmin_below, tmax_above, st, tv);
+            else leaf_step<false>(sc.leaves, sc.prims, r, tmin, closest, st, tv);
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }
@@ -425,13 +504,13 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 }
 
 // The same walk for a whole wave that traces together.  Node steps outnumber leaf steps
-// about eight to one, so letting both bodies run in every iteration would execute the
+// about five to one, so letting both bodies run in every iteration would execute the
 // sphere code for a handful of lanes each time.  Instead the wave counts, per iteration,
 // how many of its walking lanes stand at a leaf: the leaf body runs only when at least
 // LEAF_QUORUM lanes wait for it (or nobody wants a node); otherwise the node body runs.
 //
-// LDS_TREE: nodes and spheres are all in LDS and the stack never spills.  Otherwise the
-// first tree.n_lnodes nodes are in LDS, deeper nodes and all spheres in device memory, and
+// LDS_TREE: nodes and leaves are all in LDS and the stack never spills.  Otherwise the
+// first tree.n_lnodes nodes are in LDS, deeper nodes and all leaves in device memory, and
 // stack entries beyond st.cap spill to device memory.
 //
 // `work` grows by 1 per node iteration and by 3 per leaf iteration this lane took part in: the
@@ -440,11 +519,13 @@ template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK>
 __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
                                                     double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work) {
     constexpr bool SPILL = !LDS_TREE;
+    const float tmin_below = below(tmin);
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
         Trav tv;
         if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
+        const float tmax_above = above(closest);
         while (tv.cur != REF_NONE) {
             const bool at_node = tv.cur >= 0;
             const int n_node = __popcll(__ballot(at_node));
@@ -452,14 +533,14 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
             if (n_leaf >= LEAF_QUORUM || n_node == 0) {
                 if (COUNT_WORK) work += 3;
                 if (!at_node) {
-                    if (LDS_TREE) leaf_step_lds<SPILL>(tree.lprims, r, tmin, closest, st, tv);
-                    else leaf_step<SPILL>(tree.prims, r, tmin, closest, st, tv);
+                    if (LDS_TREE) leaf_step_lds<SPILL>(tree.lleaves, r, tmin, closest, st, tv);
+                    else leaf_step<SPILL>(tree.leaves, tree.prims, r, tmin, closest, st, tv);
                 }
             } else {
                 if (COUNT_WORK) work += 1;
                 if (at_node) {
-                    if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin, closest, st, tv);
-                    else node_step<SPILL>(tree.nodes, r, tmin, closest, st, tv);
+                    if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin_below, tmax_above, st, tv);
+                    else node_step<SPILL>(tree.nodes, r, tmin_below, tmax_above, st, tv);
                 }
             }
         }

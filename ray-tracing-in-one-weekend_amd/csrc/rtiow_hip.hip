@@ -149,30 +149,32 @@ template <class AccT, bool LDS_TREE, int WAVES, bool COSTING>
 __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
-                                                       uint32_t n_lprims, uint32_t stack_cap, int *spill,
+                                                       uint32_t n_lleaves, uint32_t stack_cap, int *spill,
                                                        const uint32_t *tile_order, uint32_t *tile_cost, uint32_t tile_shift) {
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // LDS: [tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][spheres]
+    // LDS: [tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][leaves]
     double *tile_sum = reinterpret_cast<double *>(lds_raw) + wave * 192;
     char *ltree = lds_raw + kRenderWaves * 192 * sizeof(double) + (size_t)stack_cap * kRenderBlock * sizeof(int);
     const LaneStack st = {reinterpret_cast<int *>(lds_raw + kRenderWaves * 192 * sizeof(double)) + tid, kRenderBlock, (int)stack_cap,
                           spill ? spill + (size_t)blockIdx.x * kRenderBlock + tid : nullptr, (int)(gridDim.x * kRenderBlock)};
-    TreeView tree = {sc.nodes, sc.prims, nullptr, nullptr, (int32_t)n_lnodes};
+    TreeView tree = {sc.nodes, sc.leaves, sc.prims, nullptr, nullptr, (int32_t)n_lnodes};
     {
-        char *lnodes = ltree, *lprims = ltree + (size_t)n_lnodes * LNODE_STRIDE;
-        for (uint32_t i = tid; i < n_lnodes * 15u; i += kRenderBlock) {   // 15 doubles of a node record are copied
+        char *lnodes = ltree, *lleaves = ltree + (((size_t)n_lnodes * LNODE_STRIDE + 7) & ~(size_t)7);
+        for (uint32_t i = tid; i < n_lnodes * 15u; i += kRenderBlock) {   // 15 words of a node record are copied
             const uint32_t n = i / 15u, w = i % 15u;
-            const double *src = reinterpret_cast<const double *>(sc.nodes + n);
-            reinterpret_cast<double *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = src[w];
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.nodes + n);
+            reinterpret_cast<uint32_t *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = src[w];
         }
-        for (uint32_t i = tid; i < n_lprims * 11u; i += kRenderBlock) {   // 11 doubles of a sphere record
-            const uint32_t n = i / 11u, w = i % 11u;
-            const double *src = reinterpret_cast<const double *>(sc.prims + n);
-            reinterpret_cast<double *>(lprims + (size_t)n * LPRIM_STRIDE)[w] = src[w];
+        for (uint32_t i = tid; i < n_lleaves * 28u; i += kRenderBlock) {   // 6 doubles of the box, 11 of each sphere record
+            const uint32_t n = i / 28u, w = i % 28u;
+            double v;
+            if (w < 6u) v = sc.leaves[n].box[w];
+            else v = reinterpret_cast<const double *>(sc.prims + 2u * n + (w - 6u) / 11u)[(w - 6u) % 11u];
+            reinterpret_cast<double *>(lleaves + (size_t)n * LLEAF_STRIDE)[w] = v;
         }
-        tree.lnodes = lnodes; tree.lprims = lprims;
+        tree.lnodes = lnodes; tree.lleaves = lleaves;
         __syncthreads();
     }
 
@@ -365,6 +367,7 @@ struct rt_scene {
     int device = 0;
     DScene d{};
     dev_buf<DNode> nodes;
+    dev_buf<DLeaf> leaves;
     dev_buf<DPrim> prims;
     dev_buf<DItem> items;
     dev_buf<DMat> mats;
@@ -381,7 +384,7 @@ struct rt_scene {
     // shape of the render kernel for this scene (see k_render)
     bool render_lds_tree = false;
     int render_waves = kWavesMin;            // per SIMD
-    uint32_t render_lnodes = 0, render_lprims = 0, render_stack_cap = 0;
+    uint32_t render_lnodes = 0, render_lleaves = 0, render_stack_cap = 0;
     size_t render_lds_bytes = 0;
     uint32_t n_nodes_dev = 0, n_prims_dev = 0;
     int n_cus = 256;
@@ -392,11 +395,12 @@ namespace {
 struct flattener {
     const rt_scene_desc *desc;
     std::vector<DNode> nodes;
-    std::vector<DPrim> prims;
+    std::vector<DLeaf> leaf_boxes;   // per leaf: the reference's box, tested in double
+    std::vector<DPrim> prims;        // two entries per leaf (the second unused when the leaf holds one sphere)
     uint32_t max_depth = 0;
     const char *error = nullptr;
 
-    // appends a primitive; returns its leaf-reference bits for slot `second`
+    // fills a primitive entry; returns its leaf-reference bits for slot `second`
     int32_t emit_prim(int32_t id, bool second, bool &safe) {
         const rt_prim_desc &p = desc->prims[id];
         DPrim d;
@@ -415,17 +419,34 @@ struct flattener {
         // a sphere that never moves stays inside the box the reference gives it
         safe = !moving;
         prims.push_back(d);
-        if (prims.size() >= (size_t)LEAF_INDEX_MASK) error = "more than 2^28 primitives";
         return moving ? (second ? LEAF_MOVING1 : LEAF_MOVING0) : 0;
     }
 
-    int32_t leaf_of(int32_t prim_a, int32_t prim_b, bool &safe) {
+    // appends a leaf of one sphere (prim_b == prim_a) or two; `box` is the box the reference tests
+    // before it tries them (min x, max x, min y, ...; unbounded when it tries them unconditionally)
+    int32_t leaf_of(int32_t prim_a, int32_t prim_b, const double *box, bool &safe) {
         bool sa = true, sb = true;
-        int32_t ref = LEAF_BIT | (int32_t)prims.size();
+        if (leaf_boxes.size() >= (size_t)LEAF_INDEX_MASK) { error = "more than 2^27 leaves"; return REF_NONE; }
+        int32_t ref = LEAF_BIT | (int32_t)leaf_boxes.size();
+        DLeaf lf;
+        memcpy(lf.box, box, sizeof lf.box);
+        leaf_boxes.push_back(lf);
         ref |= emit_prim(prim_a, false, sa);
         if (prim_b != prim_a) ref |= LEAF_TWO | emit_prim(prim_b, true, sb);
+        else { DPrim unused; memset(&unused, 0, sizeof unused); unused.orig = -1; prims.push_back(unused); }
         safe = sa && sb;
+        if (safe) ref |= LEAF_SAFE;
         return ref;
+    }
+
+    // a child's box in the node: single precision, rounded outward
+    static void set_child_box(DNode &n, int c, const double *box) {
+        for (int k = 0; k < 6; ++k) {
+            float f = (float)box[k];
+            if (k & 1) { if ((double)f < box[k]) f = std::nextafterf(f, HUGE_VALF); }
+            else { if ((double)f > box[k]) f = std::nextafterf(f, -HUGE_VALF); }
+            n.bx[c][k] = f;
+        }
     }
 
     // returns the device reference (node index or leaf) built for description node `id`
@@ -441,7 +462,9 @@ struct flattener {
                 return REF_NONE;
             }
         }
-        if (ref[0] < 0 && ref[1] < 0) return leaf_of(~ref[0], ~ref[1], safe);   // bvh_node.cpp:31-37
+        double own[6];
+        for (int a = 0; a < 3; ++a) { own[2 * a] = nd.box_min[a]; own[2 * a + 1] = nd.box_max[a]; }
+        if (ref[0] < 0 && ref[1] < 0) return leaf_of(~ref[0], ~ref[1], own, safe);   // bvh_node.cpp:31-37
 
         if (depth + 1 > max_depth) max_depth = depth + 1;
         const int me = (int)nodes.size();
@@ -452,14 +475,15 @@ struct flattener {
         for (int c = 0; c < 2; ++c) {
             if (ref[c] >= 0) {
                 const rt_node_desc &ch = desc->nodes[ref[c]];
-                for (int a = 0; a < 3; ++a) { out.bx[c][2 * a] = ch.box_min[a]; out.bx[c][2 * a + 1] = ch.box_max[a]; }
+                double cb[6];
+                for (int a = 0; a < 3; ++a) { cb[2 * a] = ch.box_min[a]; cb[2 * a + 1] = ch.box_max[a]; }
+                set_child_box(out, c, cb);
                 out.child[c] = build(ref[c], depth + 1, safe_c[c]);
                 if (error) return REF_NONE;
             } else {
-                // a primitive beside a subtree: the reference tests it without a box, which
-                // an unbounded box reproduces (every slab interval is (-inf, +inf))
-                for (int a = 0; a < 3; ++a) { out.bx[c][2 * a] = -HUGE_VAL; out.bx[c][2 * a + 1] = HUGE_VAL; }
-                out.child[c] = leaf_of(~ref[c], ~ref[c], safe_c[c]);
+                // a primitive beside a subtree: the reference tries it whenever this node's box is hit
+                set_child_box(out, c, own);
+                out.child[c] = leaf_of(~ref[c], ~ref[c], own, safe_c[c]);
             }
         }
         if (safe_c[0]) out.flags |= NF_SAFE0;
@@ -493,14 +517,14 @@ struct flattener {
         leaf_rec lr;
         for (int a = 0; a < 3; ++a) { lr.box[2 * a] = nd.box_min[a]; lr.box[2 * a + 1] = nd.box_max[a]; }
         if (ref[0] < 0 && ref[1] < 0) {
-            lr.ref = leaf_of(~ref[0], ~ref[1], lr.safe);
+            lr.ref = leaf_of(~ref[0], ~ref[1], lr.box, lr.safe);
             leaves.push_back(lr);
             return;
         }
         for (int c = 0; c < 2; ++c) {
             if (ref[c] >= 0) collect(ref[c], depth + 1);
             else {   // a primitive beside a subtree is tested whenever this node's box is hit
-                lr.ref = leaf_of(~ref[c], ~ref[c], lr.safe);
+                lr.ref = leaf_of(~ref[c], ~ref[c], lr.box, lr.safe);
                 leaves.push_back(lr);
             }
             if (error) return;
@@ -579,21 +603,23 @@ struct flattener {
         DNode out;
         memset(&out, 0, sizeof out);
         bool safe_c[2];
+        double cb[2][6];   // the children's boxes: exact unions of the reference's leaf boxes
         const size_t beg[2] = {first, pos}, cnt[2] = {pos - first, first + count - pos};
         for (int c = 0; c < 2; ++c) {
             if (cnt[c] == 1) {
                 out.child[c] = leaves[beg[c]].ref;
-                memcpy(out.bx[c], leaves[beg[c]].box, sizeof out.bx[c]);
+                memcpy(cb[c], leaves[beg[c]].box, sizeof cb[c]);
                 safe_c[c] = leaves[beg[c]].safe;
             } else {
-                out.child[c] = cluster(beg[c], cnt[c], depth + 1, out.bx[c], safe_c[c]);
+                out.child[c] = cluster(beg[c], cnt[c], depth + 1, cb[c], safe_c[c]);
             }
+            set_child_box(out, c, cb[c]);
         }
         if (safe_c[0]) out.flags |= NF_SAFE0;
         if (safe_c[1]) out.flags |= NF_SAFE1;
         safe = safe_c[0] && safe_c[1];
-        memcpy(out_box, out.bx[0], sizeof out.bx[0]);
-        grow(out_box, out.bx[1]);
+        memcpy(out_box, cb[0], sizeof cb[0]);
+        grow(out_box, cb[1]);
         nodes[me] = out;
         return me;
     }
@@ -709,7 +735,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             di.has_box = 1;
             di.ref = reference_layout ? fl.build(it.index, 0, safe) : fl.build_clustered(it.index, safe);
         } else {
-            di.ref = fl.leaf_of(it.index, it.index, safe);
+            const double unbounded[6] = {-HUGE_VAL, HUGE_VAL, -HUGE_VAL, HUGE_VAL, -HUGE_VAL, HUGE_VAL};   // object_list.cpp:18 tries it directly
+            di.ref = fl.leaf_of(it.index, it.index, unbounded, safe);
         }
         if (fl.error) return fail(RT_E_UNSUPPORTED, "%s", fl.error);
         items.push_back(di);
@@ -728,7 +755,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     {
         const size_t sums = 192 * sizeof(double);   // per wave
         auto whole_tree = [&](int waves) {
-            return 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + fl.nodes.size() * LNODE_STRIDE + fl.prims.size() * LPRIM_STRIDE;
+            return 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
+                   fl.leaf_boxes.size() * LLEAF_STRIDE;
         };
         const char *force_waves = getenv("RTIOW_RENDER_WAVES");   // "3" keeps the 768-thread shape (tests)
         const int waves_fit = whole_tree(kWavesMax) <= kLdsBudget && !(force_waves && atoi(force_waves) == kWavesMin) ? kWavesMax : kWavesMin;
@@ -741,7 +769,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             s->render_lds_tree = true;
             s->render_waves = waves_fit;
             s->render_lnodes = (uint32_t)fl.nodes.size();
-            s->render_lprims = (uint32_t)fl.prims.size();
+            s->render_lleaves = (uint32_t)fl.leaf_boxes.size();
             s->render_stack_cap = stack_depth;
             s->render_lds_bytes = whole;
         } else {
@@ -749,12 +777,12 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(1, atoi(force_cap)));
             s->render_waves = kWavesMax;
             const size_t base = 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
-            size_t k = std::min(fl.nodes.size(), (kLdsBudget - base) / LNODE_STRIDE);
+            size_t k = std::min(fl.nodes.size(), (kLdsBudget - base - 8) / LNODE_STRIDE);
             if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
             fl.stage_top_levels(k, items);
             s->render_lnodes = (uint32_t)k;
             s->render_stack_cap = cap;
-            s->render_lds_bytes = base + k * LNODE_STRIDE;
+            s->render_lds_bytes = base + ((k * LNODE_STRIDE + 7) & ~(size_t)7);
             spill_ints = (size_t)(stack_depth - cap) * s->n_cus * 256 * kWavesMax;
         }
     }
@@ -792,6 +820,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
 
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
+    if (e == hipSuccess) e = s->leaves.upload(fl.leaf_boxes.data(), fl.leaf_boxes.size());
     if (e == hipSuccess) e = s->prims.upload(fl.prims.data(), fl.prims.size());
     if (e == hipSuccess) e = s->items.upload(items.data(), items.size());
     if (e == hipSuccess) e = s->mats.upload(mats.data(), mats.size());
@@ -816,7 +845,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         delete s;
         return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
     }
-    s->d.nodes = s->nodes.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
+    s->d.nodes = s->nodes.p; s->d.leaves = s->leaves.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = stack_depth;
@@ -824,11 +853,11 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->n_nodes_dev = (uint32_t)fl.nodes.size();
     s->n_prims_dev = (uint32_t)fl.prims.size();
     if (getenv("RTIOW_VERBOSE"))
-        fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render kernel: %s, %u nodes and %u spheres in LDS, "
+        fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render kernel: %s, %u nodes and %u leaves in LDS, "
                         "%u stack entries in LDS, %zu B of LDS (budget %zu), %zu B of spill\n",
-                fl.nodes.size(), fl.prims.size(), fl.max_depth, reference_layout ? "reference" : "re-clustered",
+                fl.nodes.size(), (size_t)desc->n_prims, fl.max_depth, reference_layout ? "reference" : "re-clustered",
                 s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
-                s->render_lnodes, s->render_lprims,
+                s->render_lnodes, s->render_lleaves,
                 s->render_stack_cap, s->render_lds_bytes, kLdsBudget, spill_ints * sizeof(int));
     *out = s;
     return RT_OK;
@@ -1000,7 +1029,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
 #define RT_LAUNCH(T, L, W, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                           \
     hipLaunchKernelGGL((k_render<T, L, W, C>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,      \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
-                       scene->render_lnodes, scene->render_lprims, scene->render_stack_cap, scene->spill.p, ORDER, COST, SHIFT)
+                       scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, scene->spill.p, ORDER, COST, SHIFT)
 #define RT_LAUNCH_SHAPE(T, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
     do {                                                                                                                  \
         if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \

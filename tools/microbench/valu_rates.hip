@@ -56,6 +56,10 @@ KERNEL_F64(k_sqrt_f64, "v_sqrt_f64 %0, %0")
 KERNEL_F64(k_rsq_f64, "v_rsq_f64 %0, %0")
 KERNEL_F64(k_div_fixup_f64, "v_div_fixup_f64 %0, %0, %1, %2")
 KERNEL_F64(k_mov_b64, "v_mov_b64 %0, %1")
+KERNEL_U32(k_fma_f32, "v_fma_f32 %0, %0, %2, %1")
+KERNEL_U32(k_max3_f32, "v_max3_f32 %0, %0, %1, %2")
+KERNEL_U32(k_max_f32, "v_max_f32 %0, %0, %1")
+KERNEL_F64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %2, %1")
 KERNEL_U32(k_add_u32, "v_add_u32 %0, %0, %1")
 KERNEL_U32(k_xor_b32, "v_xor_b32 %0, %0, %1")
 KERNEL_U32(k_lshl_b32, "v_lshlrev_b32 %0, 7, %0")
@@ -113,6 +117,7 @@ int main() {
         {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64}, {"v_fma_f64", k_fma_f64}, {"v_max_f64", k_max_f64},
         {"v_cmp_lt_f64", k_cmp_f64}, {"v_rcp_f64", k_rcp_f64}, {"v_sqrt_f64", k_sqrt_f64}, {"v_rsq_f64", k_rsq_f64},
         {"v_div_fixup_f64", k_div_fixup_f64}, {"v_mov_b64", k_mov_b64},
+        {"v_fma_f32", k_fma_f32}, {"v_max3_f32", k_max3_f32}, {"v_max_f32", k_max_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
         {"v_add_u32", k_add_u32}, {"v_xor_b32", k_xor_b32}, {"v_lshlrev_b32", k_lshl_b32}, {"v_alignbit_b32", k_alignbit},
         {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mul_u32_u24", k_mul_u24}, {"v_cndmask_b32", k_cndmask},
         {"ds_read_b64", k_lds_read<8>}, {"ds_read_b32", k_lds_read<4>},
