@@ -35,7 +35,11 @@ struct __attribute__((aligned(16))) DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode is one 64-byte line");
 
-struct DLeaf { double box[6]; };   // the reference's box of the leaf: min x, max x, min y, max y, min z, max z
+struct DLeaf { double box[6]; };
+
+// a plane of an inner box in single precision: not above (below) the double it stands for
+__host__ __device__ inline float plane_down(double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -HUGE_VALF); return f; }
+__host__ __device__ inline float plane_up(double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, HUGE_VALF); return f; }   // the reference's box of the leaf: min x, max x, min y, max y, min z, max z
 
 // Every primitive under a SAFE child stays inside the child's box (static spheres), so
 // the descent may be skipped once the box starts beyond the best hit.  A moving sphere
@@ -131,10 +135,14 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
     c.a = vdot(r.d, r.d);
     c.ixf = (float)c.ix; c.iyf = (float)c.iy; c.izf = (float)c.iz;
     c.cxf = (float)-(r.o.x * c.ix); c.cyf = (float)-(r.o.y * c.iy); c.czf = (float)-(r.o.z * c.iz);
-    // a zero, huge or NaN direction component makes an infinite or NaN constant; the test then
-    // yields NaN bounds, and NaN bounds pass: such rays simply visit more of the tree
-    c.widen = kWidenK * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c.cxf), __builtin_fabsf(c.cyf)), __builtin_fabsf(c.czf));
-    if (!(c.cxf == c.cxf && c.cyf == c.cyf && c.czf == c.czf)) c.widen = __builtin_nanf("");
+    // A zero, huge or NaN direction component makes an infinite or NaN constant; the test then
+    // yields infinite or NaN bounds, and those pass: such rays simply visit more of the tree.
+    // The error bound is relative, which single precision only honours away from its subnormal
+    // range: the floor 2^-100 covers products and constants that underflow, and a reciprocal
+    // below 2^-100 (a direction component beyond 2^100) widens without limit.
+    // (the sum bounds the largest |c| and, unlike a maximum, hands a NaN on)
+    const float smallest = __builtin_fminf(__builtin_fminf(__builtin_fabsf(c.ixf), __builtin_fabsf(c.iyf)), __builtin_fabsf(c.izf));
+    c.widen = kWidenK * (__builtin_fabsf(c.cxf) + __builtin_fabsf(c.cyf) + __builtin_fabsf(c.czf)) + (smallest >= 0x1p-100f ? 0x1p-100f : HUGE_VALF);
     return c;
 }
 

@@ -441,12 +441,7 @@ struct flattener {
 
     // a child's box in the node: single precision, rounded outward
     static void set_child_box(DNode &n, int c, const double *box) {
-        for (int k = 0; k < 6; ++k) {
-            float f = (float)box[k];
-            if (k & 1) { if ((double)f < box[k]) f = std::nextafterf(f, HUGE_VALF); }
-            else { if ((double)f > box[k]) f = std::nextafterf(f, -HUGE_VALF); }
-            n.bx[c][k] = f;
-        }
+        for (int k = 0; k < 6; ++k) n.bx[c][k] = (k & 1) ? plane_up(box[k]) : plane_down(box[k]);
     }
 
     // returns the device reference (node index or leaf) built for description node `id`
@@ -500,7 +495,9 @@ struct flattener {
     // of every box that contains it passes too (aabb.cpp:8-57 with the same ray and
     // interval).  "All ancestors' boxes hit" is therefore equivalent to "the leaf's box is
     // hit", and ANY tree whose inner boxes are exact unions of the reference's leaf boxes
-    // reaches exactly the reference's leaves.  The reference's random-axis median split
+    // reaches exactly the reference's leaves.  (The device keeps those unions in single
+    // precision, rounded outward, with a conservative test, and repeats the reference's exact
+    // test on each leaf's own box: see rt_device.hpp.)  The reference's random-axis median split
     // costs ~19 node visits per ray on the 485-sphere scene; a surface-area-heuristic tree
     // over the same leaves costs ~12.  Primitives keep the reference's left-to-right
     // numbering, which is what decides ties.

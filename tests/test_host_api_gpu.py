@@ -111,3 +111,13 @@ def test_frame_driver_writes_the_reference_ppm_and_its_binary_twin(tmp_path, rt)
     w.close()
     expect = (255.99 * np.sqrt(sums.astype(np.float64) / 8)).astype(np.int64)
     assert np.abs(expect - p3).max() <= 1 and (expect != p3).mean() < 0.01
+
+
+def test_single_precision_node_test_is_conservative():
+    # The inner nodes of the device tree are tested in single precision; everything exact rests on
+    # that test never rejecting a box the reference's double-precision test accepts.  The checker
+    # aims rays at faces, edges and corners of random boxes, nudged by ulps, at many scales.
+    exe = os.path.join(ROOT, "ray-tracing-in-one-weekend_amd", "csrc", "conservative_check")
+    r = subprocess.run([exe, "400000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 violations" in r.stdout
