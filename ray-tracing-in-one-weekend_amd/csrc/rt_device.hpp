@@ -474,16 +474,21 @@ __device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prim
 
 // Starts the walk of one world item: tests the root box as bvh_node::hit does first
 // (bvh_node.cpp:53).  Returns false when the item cannot be hit.
+// A bare sphere in the world's list (has_box = 0) is tried on the spot, as object_list.cpp:18 does,
+// and the walk stays empty.
 __device__ __forceinline__ bool item_begin(const DScene &sc, uint32_t item, const RayCtx &r, double tmin, double tmax, Trav &tv) {
     const DItem *it = sc.items + item;
     tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.bt_above = 0; tv.cur = REF_NONE;
-    if (it->has_box) {
-        double bx[6], entry;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) bx[k] = it->box[k];
-        if (!box_test(bx, r, tmin, tmax, entry)) return false;
+    const int32_t ref = it->ref;
+    if (!it->has_box) {
+        leaf_candidate(sc.prims, 2 * (ref & LEAF_INDEX_MASK), ref & LEAF_MOVING0, r, tmin, tmax, tv);
+        return true;
     }
-    tv.cur = it->ref;
+    double bx[6], entry;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bx[k] = it->box[k];
+    if (!box_test(bx, r, tmin, tmax, entry)) return false;
+    tv.cur = ref;
     return true;
 }
 
