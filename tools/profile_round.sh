@@ -26,7 +26,7 @@ for f in glob.glob(os.path.join(out, "full_*_counter_collection.csv")):
             tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
 # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes,
 # so the read side is doubled (MI355X_MICROARCH.md, HBM section).
-res = {"config": "bench.py defaults (book1, 1920x1080, 1024 spp), one k_render launch",
+res = {"config": "bench.py defaults (book1, 1920x1080, 1024 spp), one step: costing pass + main k_render launch",
        "FETCH_SIZE_KiB": tot.get("FETCH_SIZE"), "WRITE_SIZE_KiB": tot.get("WRITE_SIZE"),
        "hbm_bytes_per_launch": (2 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024}
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
