@@ -269,12 +269,13 @@ __device__ __forceinline__ bool sphere_root(v3 c, double radius, const RayCtx &r
     bool hit = false;
     if (disc > 0) {
         double root = sqrt(disc);
-        double t1 = (-b - root) / r.a;
-        double t2 = (-b + root) / r.a;
-        bool ok1 = t1 < tmax && t1 > tmin;
-        bool ok2 = t2 < tmax && t2 > tmin;
-        t_out = ok1 ? t1 : t2;
-        hit = ok1 || ok2;
+        double t = (-b - root) / r.a;
+        hit = t < tmax && t > tmin;
+        if (!hit) {   // the farther root only when the nearer one is not accepted (sphere.cpp:31)
+            t = (-b + root) / r.a;
+            hit = t < tmax && t > tmin;
+        }
+        t_out = t;
     }
     return hit;
 }
