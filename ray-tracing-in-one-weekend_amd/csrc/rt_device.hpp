@@ -65,8 +65,8 @@ struct __attribute__((aligned(16))) DPrim {
 static_assert(sizeof(DPrim) == 96, "DPrim layout");
 
 // One entry of the world's object_list.  ref is a node index or a leaf reference;
-// has_box = 0 for a bare primitive in the list (object_list.cpp:18 tests it directly).
-struct DItem { int32_t ref; uint32_t has_box; uint32_t pad[2]; double box[6]; };
+// has_box = 0 for a bare primitive in the list (object_list.cpp:18 tries it directly).
+struct DItem { int32_t ref; uint32_t has_box; };
 struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; };
 struct DTex { uint32_t kind; uint32_t even, odd; uint32_t pad; double c[3]; };
 
@@ -473,24 +473,16 @@ __device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prim
     tv.cur = trav_pop<SPILL>(tv, st);
 }
 
-// Starts the walk of one world item: tests the root box as bvh_node::hit does first
-// (bvh_node.cpp:53).  Returns false when the item cannot be hit.
-// A bare sphere in the world's list (has_box = 0) is tried on the spot, as object_list.cpp:18 does,
-// and the walk stays empty.
-__device__ __forceinline__ bool item_begin(const DScene &sc, uint32_t item, const RayCtx &r, double tmin, double tmax, Trav &tv) {
+// Starts the walk of one world item.  The reference tests the root's box first (bvh_node.cpp:53);
+// that test is implied by the exact test of every leaf's box (a leaf's box lies inside the root's),
+// so the walk starts at the root's children right away.  A bare sphere in the world's list
+// (has_box = 0) is tried on the spot, as object_list.cpp:18 does, and the walk stays empty.
+__device__ __forceinline__ void item_begin(const DScene &sc, uint32_t item, const RayCtx &r, double tmin, double tmax, Trav &tv) {
     const DItem *it = sc.items + item;
     tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.bt_above = 0; tv.cur = REF_NONE;
     const int32_t ref = it->ref;
-    if (!it->has_box) {
-        leaf_candidate(sc.prims, 2 * (ref & LEAF_INDEX_MASK), ref & LEAF_MOVING0, r, tmin, tmax, tv);
-        return true;
-    }
-    double bx[6], entry;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bx[k] = it->box[k];
-    if (!box_test(bx, r, tmin, tmax, entry)) return false;
-    tv.cur = ref;
-    return true;
+    if (!it->has_box) leaf_candidate(sc.prims, 2 * (ref & LEAF_INDEX_MASK), ref & LEAF_MOVING0, r, tmin, tmax, tv);
+    else tv.cur = ref;
 }
 
 // object_list::hit (object_list.cpp:12-26) over the world's items, one ray per lane:
@@ -504,7 +496,7 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
         Trav tv;
-        if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
+        item_begin(sc, i, r, tmin, closest, tv);
         const float tmax_above = above(closest);
         while (tv.cur != REF_NONE) {
             if (tv.cur >= 0) node_step<false>(sc.nodes, r, tmin_below, tmax_above, st, tv);
@@ -538,7 +530,7 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
         Trav tv;
-        if (!item_begin(sc, i, r, tmin, closest, tv)) continue;
+        item_begin(sc, i, r, tmin, closest, tv);
         const float tmax_above = above(closest);
         while (tv.cur != REF_NONE) {
             const bool at_node = tv.cur >= 0;

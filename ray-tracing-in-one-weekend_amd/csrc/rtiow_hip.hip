@@ -727,8 +727,6 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         memset(&di, 0, sizeof di);
         bool safe;
         if (it.is_bvh) {
-            const rt_node_desc &root = desc->nodes[it.index];
-            for (int a = 0; a < 3; ++a) { di.box[2 * a] = root.box_min[a]; di.box[2 * a + 1] = root.box_max[a]; }
             di.has_box = 1;
             di.ref = reference_layout ? fl.build(it.index, 0, safe) : fl.build_clustered(it.index, safe);
         } else {
