@@ -117,8 +117,8 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // The pixel/sample loop (main.cpp:126-141) with ray_colour (main.cpp:30-50) unrolled
 // into one loop over ray segments.
 //
-// Persistent blocks: the grid is one block per CU; each wave draws 8x8 pixel tiles from
-// a device-wide queue until the frame is done, so no CU idles behind a slow tile.  When
+// Persistent blocks: the grid is one block per CU; each wave draws pixel tiles from a
+// device-wide queue until the frame is done, so no CU idles behind a slow tile.  When
 // the tree fits, the block first copies it into LDS (nodes and spheres, re-strided
 // against bank conflicts) and every traversal step reads LDS instead of the vector cache.
 //
