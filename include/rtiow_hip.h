@@ -139,8 +139,11 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
  * GPU, nx*ny*3 values of accum_type, row-major, top image row first), asynchronously
  * on `stream` (a hipStream_t, or NULL).  stats may be NULL; when given, the call
  * synchronises the stream and fills it.  At most 2^24 samples per pixel per call.  A scene
- * carries the frame's tile queue: renders of ONE scene must not overlap in time (use one
- * scene per stream if they must). */
+ * carries the frame's tile queue and tile order: renders of ONE scene must not overlap in
+ * time (use one scene per stream if they must).  Frames of 32 samples per pixel or more are
+ * preceded by a short costing pass on the same stream (tiles are then rendered dearest
+ * first); its two small device buffers are allocated on the first such call for an image
+ * size, which may synchronise the device.  The image does not depend on any of this. */
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 
