@@ -10,6 +10,7 @@ mt19937 frames the comparison is statistical, with the Monte-Carlo noise floor m
 from two reference seeds.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -81,6 +82,76 @@ def test_object_hit_random_rays_against_oracle(worlds, orc):
         assert np.array_equal(h["p"][m], tpn[m, 1:4])
         assert np.array_equal(h["normal"][m], tpn[m, 4:7])
         assert 0.2 < m.mean() < 0.99
+
+
+def _random_recipe(rng, path):
+    """A random world: bare spheres and bvh groups of awkward sizes, static and moving spheres with
+    assorted time ranges, coincident centres (ties), flat and huge radii, at a random scale."""
+    scale = float(rng.choice([0.01, 1.0, 1.0, 30.0, 1e4]))
+    lines = ["rtiow-recipe 1", "texture constant 0.5 0.5 0.5", "material lambertian 0", "material metal 0.8 0.8 0.8 0.1", "material dielectric 1.5"]
+
+    def sphere():
+        c = rng.uniform(-1, 1, 3) * scale
+        if rng.random() < 0.15:
+            c = np.round(c / scale * 2) / 2 * scale                     # a coarse lattice: coincident centres
+        r = scale * float(rng.choice([0.02, 0.05, 0.1, 0.2, 0.6])) * rng.uniform(0.5, 1.5)
+        m = int(rng.integers(0, 3))
+        if rng.random() < 0.35:
+            c1 = c + rng.uniform(-0.5, 0.5, 3) * scale
+            t0, t1 = [(0, 1), (0, 1), (0.25, 2), (-1, 3)][int(rng.integers(0, 4))]
+            return f"moving_sphere {m} " + " ".join(repr(float(v)) for v in [*c, *c1, t0, t1, r])
+        return f"sphere {m} " + " ".join(repr(float(v)) for v in [*c, r])
+
+    for _ in range(int(rng.integers(1, 5))):
+        kind = rng.random()
+        if kind < 0.3:
+            lines.append(sphere())
+        else:
+            n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 17, 40, 150]))
+            lines.append(f"bvh_begin {int(rng.integers(1, 1000))} 0 1")
+            lines += [sphere() for _ in range(n)]
+            lines.append("bvh_end")
+    path.write_text("\n".join(lines) + "\n")
+    return scale
+
+
+def test_random_worlds_against_oracle(rt, orc, tmp_path):
+    # object::hit on worlds nobody designed: every hit flag, primitive, t, p and normal must equal
+    # the oracle's to the bit, on both tree layouts
+    rng = np.random.default_rng(2024)
+    for k in range(40):
+        path = tmp_path / f"w{k}.recipe"
+        scale = _random_recipe(rng, path)
+        n = 20000
+        o = rng.uniform(-3, 3, (n, 3)) * scale
+        tgt = rng.uniform(-1.2, 1.2, (n, 3)) * scale
+        d = (tgt - o) * rng.uniform(0.05, 20, (n, 1))
+        axis = rng.integers(0, 3, n)
+        flat = rng.random(n) < 0.05
+        d[flat, axis[flat]] = 0.0                                       # rays parallel to a slab
+        rays = np.hstack([o, d, rng.uniform(-1, 1, (n, 1))])
+        tmin, tmax = (0.001, np.finfo(np.float64).max) if k % 3 else (float(rng.uniform(-2, 0.5)), float(rng.uniform(1, 50)))
+        hit, prim, tpn = orc.Scene(str(path)).trace(rays, tmin, tmax)
+        for layout in ("", "reference"):
+            if layout:
+                os.environ["RTIOW_TREE"] = layout
+            try:
+                w = rt.World(str(path))
+            finally:
+                os.environ.pop("RTIOW_TREE", None)
+            h = w.trace(rays, tmin, tmax)
+            if not layout:      # and the render kernel's walk (LDS-resident tree) on the same world
+                cam15 = np.array([3 * scale, 2 * scale, 3 * scale, 0, 0, 0, 0, 1, 0, 40, 2.0, 0.0, 4 * scale, 0, 1], dtype=np.float64)
+                got, st = w.render(rt.camera(cam15), 40, 20, 0, 3, 100 + k, rt.RT_ACCUM_F64)
+                exp, counters = orc.Scene(str(path)).render(cam15, 40, 20, 0, 3, 100 + k, orc.ORC_RNG_STREAM)
+                assert st.rays == counters.rays, k
+                np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+            w.close()
+            assert np.array_equal(h["hit"], hit.astype(np.int32)), (k, layout)
+            assert np.array_equal(h["prim"], prim), (k, layout)
+            m = hit == 1
+            assert np.array_equal(h["t"][m], tpn[m, 0]), (k, layout)
+            assert np.array_equal(h["p"][m], tpn[m, 1:4]) and np.array_equal(h["normal"][m], tpn[m, 4:7]), (k, layout)
 
 
 def test_degenerate_rays(worlds, orc):
