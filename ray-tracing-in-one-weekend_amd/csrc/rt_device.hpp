@@ -280,6 +280,23 @@ __device__ __forceinline__ bool sphere_root(v3 c, double radius, const RayCtx &r
     return hit;
 }
 
+// Lane-utilisation counters of the render kernel, compiled in with -DRT_LANE_STATS (the
+// "lanestats" make target) and empty otherwise.  Phase k counts how often a wave executed it
+// (c[2k]) and with how many lanes (c[2k+1]): 0 node step, 1 leaf step, 2 round (lanes with a live
+// path), 3 hit shading, 4 sky, 5 claiming new paths.
+struct LaneStats {
+#ifdef RT_LANE_STATS
+    unsigned long long *c = nullptr;   // 12 slots of the wave in device memory; null = not counting
+    // whichever lanes are active here, exactly one of them books the execution for the wave
+    __device__ __forceinline__ void add(int phase, uint32_t lanes) {
+        const unsigned long long active = __ballot(true);
+        if (c && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) { c[2 * phase] += 1; c[2 * phase + 1] += lanes; }
+    }
+#else
+    __device__ __forceinline__ void add(int, uint32_t) {}
+#endif
+};
+
 // ------------------------------------------------------------------ traversal ----
 // bvh_node::hit (bvh_node.cpp:52-69) as a walk with an explicit stack.  The reference
 // visits both children of every node whose box is hit, with the interval it was given,
@@ -523,7 +540,8 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 // lane that walked longest has counted what the wave executed, in units of roughly a node step.
 template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK>
 __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
-                                                    double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work) {
+                                                    double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work,
+                                                    LaneStats &stats) {
     constexpr bool SPILL = !LDS_TREE;
     const float tmin_below = below(tmin);
     double closest = tmax;
@@ -537,12 +555,14 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
             const int n_node = __popcll(__ballot(at_node));
             const int n_leaf = __popcll(__ballot(!at_node));
             if (n_leaf >= LEAF_QUORUM || n_node == 0) {
+                stats.add(1, (uint32_t)n_leaf);
                 if (COUNT_WORK) work += 3;
                 if (!at_node) {
                     if (LDS_TREE) leaf_step_lds<SPILL>(tree.lleaves, r, tmin, closest, st, tv);
                     else leaf_step<SPILL>(tree.leaves, tree.prims, r, tmin, closest, st, tv);
                 }
             } else {
+                stats.add(0, (uint32_t)n_node);
                 if (COUNT_WORK) work += 1;
                 if (at_node) {
                     if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin_below, tmax_above, st, tv);

@@ -141,6 +141,11 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // entries spill to it.
 constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
+#ifdef RT_LANE_STATS
+constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics slots per wave of up to 1024 blocks
+#else
+constexpr size_t kCounters = 4;                         // rays, tile queue, and the same for the costing pass
+#endif
 constexpr uint32_t kOrderMinSamples = 32;               // frames at least this deep get their tiles ordered by cost
 
 // COSTING: the pass that ranks the tiles -- the same walk over a few samples, but instead of
@@ -182,6 +187,10 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
     const uint32_t tile_side = 1u << tile_shift, tile_px = tile_side * tile_side;
     const uint32_t tiles_x = (nx + tile_side - 1) >> tile_shift, tiles_y = (ny + tile_side - 1) >> tile_shift, n_tiles = tiles_x * tiles_y;
     unsigned long long nrays = 0;
+    LaneStats lane_stats;
+#ifdef RT_LANE_STATS
+    if (!COSTING) lane_stats.c = counters + 4 + 12 * (blockIdx.x * 16 + wave);   // zeroed by rt_render
+#endif
 
     for (;;) {
         uint32_t tile = 0;
@@ -233,13 +242,16 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                 if (next >= total) break;
                 continue;
             }
+            lane_stats.add(2, (uint32_t)__popcll(__ballot(alive)));
+            if (want != 0) lane_stats.add(5, (uint32_t)__popcll(want));
             if (alive) {
                 const RayCtx ctx = make_ctx(r);
                 double t;
                 int prim;
                 ++nrays;
                 if (COSTING) work += 8;   // claiming, set-up and shading of one segment, in node-step units
-                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE, COSTING>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work)) {
+                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE, COSTING>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats)) {
+                    lane_stats.add(3, (uint32_t)__popcll(__ballot(true)));
                     v3 p, nn, att;
                     Ray nextray;
                     hit_point(sc, prim, ctx, t, p, nn);
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                         alive = false;  // absorbed or too deep: black (main.cpp:42)
                     }
                 } else {
+                    lane_stats.add(4, (uint32_t)__popcll(__ballot(true)));
                     const v3 c = sky(r.d);
                     __hip_atomic_fetch_add(tile_sum + slot, c.x * thr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(tile_sum + 64 + slot, c.y * thr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -822,7 +835,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->texs.upload(texs.data(), texs.size());
     if (e == hipSuccess) e = s->ranfloat.upload(ranfloat.data(), ranfloat.size());
     if (e == hipSuccess) e = s->perm.upload(perm.data(), perm.size());
-    if (e == hipSuccess) e = s->counter.alloc(4);
+    if (e == hipSuccess) e = s->counter.alloc(kCounters);
     if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
     // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
     const void *kernels[9] = {reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, false>),
@@ -1013,7 +1026,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         scene->tiles_capacity = 2 * (size_t)n_tiles;
     }
     // counters[0] = rays traced, counters[1] = next tile of the frame; [2], [3]: the same for the costing pass
-    HIP_TRY(hipMemsetAsync(scene->counter.p, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(scene->counter.p, 0, kCounters * sizeof(unsigned long long), stream));
     if (stats) {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
@@ -1053,6 +1066,17 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         unsigned long long rays = 0;
         HIP_TRY(hipMemcpy(&rays, scene->counter.p, sizeof rays, hipMemcpyDeviceToHost));
+#ifdef RT_LANE_STATS
+        std::vector<unsigned long long> all(kCounters);
+        HIP_TRY(hipMemcpy(all.data(), scene->counter.p, kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long c[16] = {0};
+        for (size_t w = 0; w < (kCounters - 4) / 12; ++w)
+            for (int q = 0; q < 12; ++q) c[4 + q] += all[4 + 12 * w + q];
+        const char *phase[6] = {"node step", "leaf step", "round", "hit shading", "sky", "claim"};
+        for (int q = 0; q < 6; ++q)
+            fprintf(stderr, "lanes: %-11s executed %llu times by a wave, %.1f of 64 lanes, %.2f lane-visits per segment\n", phase[q], c[4 + 2 * q],
+                    c[4 + 2 * q] ? (double)c[5 + 2 * q] / (double)c[4 + 2 * q] : 0.0, rays ? (double)c[5 + 2 * q] / (double)rays : 0.0);
+#endif
         stats->kernel_ms = ms;
         stats->rays = rays;
         stats->paths = (uint64_t)pr->nx * pr->ny * (pr->sample_end - pr->sample_begin);
