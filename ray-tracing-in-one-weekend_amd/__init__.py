@@ -149,6 +149,7 @@ def host():
         lib.rth_world_recipe_ids.restype = ctypes.POINTER(ctypes.c_int32)
         lib.rth_camera.argtypes = [ctypes.c_void_p, ctypes.POINTER(rt_camera)]
         lib.rth_perlin_tables.argtypes = [ctypes.c_void_p] * 4
+        lib.rth_write_image.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         _host = lib
     return _host
 
@@ -172,6 +173,14 @@ def camera(cam15):
     if host().rth_camera(_ptr(a), ctypes.byref(out)):
         raise RtError(host().rth_last_error().decode())
     return out
+
+
+def write_image(path, sums, ns, fmt="p3"):
+    """frame::write_ppm / write_ppm_binary / write_png over per-pixel sums [ny][nx][3] of ns samples."""
+    a = np.ascontiguousarray(sums, dtype=np.float32)
+    assert a.ndim == 3 and a.shape[2] == 3
+    if host().rth_write_image(str(path).encode(), fmt.encode(), a.shape[1], a.shape[0], int(ns), _ptr(a)):
+        raise RtError(host().rth_last_error().decode())
 
 
 def perlin_tables():

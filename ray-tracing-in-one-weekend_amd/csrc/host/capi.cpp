@@ -8,6 +8,7 @@
 #include <map>
 #include <vector>
 #include <memory>
+#include <stdexcept>
 #include <string>
 
 #include "recipe.hpp"
@@ -114,6 +115,25 @@ int rth_camera(const double* cam, rt_camera* out) {
         camera const c{mt, vec3{cam[0], cam[1], cam[2]}, vec3{cam[3], cam[4], cam[5]}, vec3{cam[6], cam[7], cam[8]},
                        cam[9], cam[10], cam[11], cam[12], cam[13], cam[14]};
         *out = c.describe();
+    });
+}
+
+// Writes per-pixel sums (nx*ny*3 floats, top row first, ns samples each) the way the frame
+// class does: format "p3" (main.cpp:145-150), "p6" or "png".
+int rth_write_image(const char* path, const char* format, int nx, int ny, int ns, const float* sums) {
+    return guarded([&] {
+        std::string const fmt = format ? format : "";
+        if (nx <= 0 || ny <= 0 || !sums || !path) throw std::runtime_error("rth_write_image: bad argument");
+        if (fmt != "p3" && fmt != "p6" && fmt != "png") throw std::runtime_error("unknown image format '" + fmt + "'");
+        frame f;
+        f.nx = nx; f.ny = ny; f.ns = ns;
+        f.sums.assign(sums, sums + (size_t)nx * ny * 3);
+        std::FILE* out = std::fopen(path, "wb");
+        if (!out) throw std::runtime_error(std::string("cannot write ") + path);
+        if (fmt == "png") f.write_png(out);
+        else if (fmt == "p6") f.write_ppm_binary(out);
+        else f.write_ppm(out);
+        if (std::fclose(out) != 0) throw std::runtime_error(std::string("error writing ") + path);
     });
 }
 

@@ -8,6 +8,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -558,6 +559,78 @@ void frame::write_ppm_binary(std::FILE* out) const {
         }
         std::fwrite(row.data(), 1, row.size(), out);
     }
+}
+
+// The same bytes as an 8-bit RGB PNG.  The image data is a zlib stream of stored
+// (uncompressed) deflate blocks, so nothing beyond the C library is needed and the file is as
+// large as the P6 one; every viewer reads it.
+void frame::write_png(std::FILE* out) const {
+    static uint32_t crc_table[256];
+    if (!crc_table[1])
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+    auto be32 = [](unsigned char* p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; };
+    auto chunk = [&](char const* type, std::vector<unsigned char> const& data) {
+        unsigned char head[8], tail[4];
+        be32(head, (uint32_t)data.size());
+        std::memcpy(head + 4, type, 4);
+        uint32_t c = 0xFFFFFFFFu;
+        for (int i = 4; i < 8; ++i) c = crc_table[(c ^ head[i]) & 0xFF] ^ (c >> 8);
+        for (unsigned char b : data) c = crc_table[(c ^ b) & 0xFF] ^ (c >> 8);
+        be32(tail, c ^ 0xFFFFFFFFu);
+        std::fwrite(head, 1, 8, out);
+        if (!data.empty()) std::fwrite(data.data(), 1, data.size(), out);
+        std::fwrite(tail, 1, 4, out);
+    };
+    static unsigned char const signature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    std::fwrite(signature, 1, 8, out);
+    std::vector<unsigned char> ihdr(13, 0);
+    be32(ihdr.data(), (uint32_t)nx);
+    be32(ihdr.data() + 4, (uint32_t)ny);
+    ihdr[8] = 8;   // bits per channel
+    ihdr[9] = 2;   // RGB
+    chunk("IHDR", ihdr);
+
+    // scanlines, each led by filter type 0
+    size_t const stride = (size_t)nx * 3 + 1;
+    std::vector<unsigned char> raw(stride * (size_t)ny);
+    for (int r = 0; r < ny; ++r) {
+        unsigned char* row = raw.data() + stride * (size_t)r;
+        row[0] = 0;
+        for (int i = 0; i < nx; ++i) {
+            colour const c = pixel(i, r);
+            row[1 + (size_t)i * 3] = (unsigned char)int(255.99 * c.red());
+            row[2 + (size_t)i * 3] = (unsigned char)int(255.99 * c.green());
+            row[3 + (size_t)i * 3] = (unsigned char)int(255.99 * c.blue());
+        }
+    }
+    uint32_t a = 1, b = 0;   // Adler-32 of the scanlines
+    for (size_t i = 0; i < raw.size();) {
+        size_t const n = std::min<size_t>(raw.size() - i, 5552);
+        for (size_t k = 0; k < n; ++k) { a += raw[i + k]; b += a; }
+        a %= 65521u; b %= 65521u;
+        i += n;
+    }
+    std::vector<unsigned char> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    size_t at = 0;
+    do {
+        size_t const n = std::min<size_t>(raw.size() - at, 65535);
+        z.push_back(at + n == raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)at, raw.begin() + (long)(at + n));
+        at += n;
+    } while (at < raw.size());
+    unsigned char adler[4];
+    be32(adler, (b << 16) | a);
+    z.insert(z.end(), adler, adler + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
 }
 
 // ------------------------------------------------------------- scene builders ----

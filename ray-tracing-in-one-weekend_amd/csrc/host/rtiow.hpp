@@ -305,6 +305,7 @@ struct frame {
     colour pixel(int i, int row) const;       // supersampler::value().gamma2() of that pixel
     void write_ppm(std::FILE* out) const;     // the P3 text of main.cpp:145-150
     void write_ppm_binary(std::FILE* out) const;   // the same values as binary P6
+    void write_png(std::FILE* out) const;          // the same values as an 8-bit RGB PNG
 };
 
 // The pixel/sample loop of main.cpp:126-141 on one GPU.

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -719,9 +720,19 @@ int rt_device_count(void) {
     return n;
 }
 
+static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (!out) return fail(RT_E_INVALID, "null output handle");
     *out = nullptr;
+    try {
+        return scene_create(desc, device, out);
+    } catch (const std::bad_alloc &) {   // the flattened tree is built in host vectors
+        return fail(RT_E_INVALID, "rt_scene_create: out of host memory");
+    }
+}
+
+static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (int rc = check_desc(desc)) return rc;
     int ndev = rt_device_count();
     if (ndev <= 0) return fail(RT_E_DEVICE, "no HIP device available");
@@ -750,8 +761,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         items.push_back(di);
     }
 
-    rt_scene *s = new (std::nothrow) rt_scene;
-    if (!s) return fail(RT_E_INVALID, "out of host memory");
+    std::unique_ptr<rt_scene> owner(new rt_scene);   // freed on every early return
+    rt_scene *s = owner.get();
     s->device = device;
     {
         hipDeviceProp_t prop;
@@ -849,10 +860,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
                               reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, true>)};
     for (const void *k : kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    if (e != hipSuccess) {
-        delete s;
-        return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
     s->d.nodes = s->nodes.p; s->d.leaves = s->leaves.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
@@ -867,7 +875,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
                 s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
                 s->render_lnodes, s->render_lleaves,
                 s->render_stack_cap, s->render_lds_bytes, kLdsBudget, spill_ints * sizeof(int));
-    *out = s;
+    *out = owner.release();
     return RT_OK;
 }
 
@@ -930,7 +938,12 @@ int rt_scatter_batch(rt_scene *scene, const int32_t *prim, const rt_ray *rays, c
     if (!scene || (n && (!prim || !rays || !hits || !scattered || !attenuation || !out || !used)) || (n && k && !tape))
         return fail(RT_E_INVALID, "rt_scatter_batch: null argument");
     if (n == 0) return RT_OK;
-    std::vector<uint32_t> mat(n);
+    std::vector<uint32_t> mat;
+    try {
+        mat.resize(n);
+    } catch (const std::bad_alloc &) {
+        return fail(RT_E_INVALID, "rt_scatter_batch: out of host memory");
+    }
     for (size_t i = 0; i < n; ++i) {
         if (prim[i] < 0 || (uint32_t)prim[i] >= scene->n_prims_desc)
             return fail(RT_E_INVALID, "rt_scatter_batch: item %zu: primitive %d out of range", i, prim[i]);
@@ -1005,7 +1018,10 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render: unknown accum_type %u", pr->accum_type);
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = (hipStream_t)stream_v;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct event_pair {   // destroyed on every return
+        hipEvent_t a = nullptr, b = nullptr;
+        ~event_pair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
     const uint32_t spp = pr->sample_end - pr->sample_begin;
     // 8x8-pixel tiles fill the 64 lanes with a single sample per pixel; from 4 samples per pixel a
     // 4x4 tile does, and tiles a quarter the size leave a quarter of the imbalance at the end of
@@ -1028,9 +1044,9 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     // counters[0] = rays traced, counters[1] = next tile of the frame; [2], [3]: the same for the costing pass
     HIP_TRY(hipMemsetAsync(scene->counter.p, 0, kCounters * sizeof(unsigned long long), stream));
     if (stats) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
-        HIP_TRY(hipEventRecord(ev0, stream));
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventRecord(ev.a, stream));
     }
     dim3 grid(blocks), block(64 * waves);
     DCamera cam = to_dcamera(camera);
@@ -1060,10 +1076,10 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (stats) {
-        HIP_TRY(hipEventRecord(ev1, stream));
-        HIP_TRY(hipEventSynchronize(ev1));
+        HIP_TRY(hipEventRecord(ev.b, stream));
+        HIP_TRY(hipEventSynchronize(ev.b));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
         unsigned long long rays = 0;
         HIP_TRY(hipMemcpy(&rays, scene->counter.p, sizeof rays, hipMemcpyDeviceToHost));
 #ifdef RT_LANE_STATS
@@ -1080,8 +1096,6 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         stats->kernel_ms = ms;
         stats->rays = rays;
         stats->paths = (uint64_t)pr->nx * pr->ny * (pr->sample_end - pr->sample_begin);
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
     }
     return RT_OK;
 }

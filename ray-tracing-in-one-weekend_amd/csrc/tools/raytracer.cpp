@@ -2,7 +2,9 @@
 // one MI355X and writes the image as the reference's main() does (main.cpp:107-151):
 // "Render duration" on stderr, P3 text on stdout.  The reference fixes scene, size and
 // sample count at compile time (main.cpp:108,113); here they are flags whose defaults
-// are those constants.
+// are those constants.  --camera takes the view the reference hard-codes at main.cpp:114-120
+// (look-from, look-at, vertical field of view); --format p6 and png hold the same bytes as
+// the reference's P3 text.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +22,9 @@ using namespace rtiow;
 static int usage() {
     std::fprintf(stderr,
                  "usage: raytracer [--scene two_perlin|book1|book2|stress|FILE.recipe] [--nx N] [--ny N] [--ns N]\n"
-                 "                 [--seed S] [--scene-seed S] [--spheres N] [--device D] [--aperture A] [--out FILE.ppm] [--binary]\n");
+                 "                 [--seed S] [--scene-seed S] [--spheres N] [--device D] [--aperture A] [--focus F]\n"
+                 "                 [--camera FX,FY,FZ,AX,AY,AZ,VFOV] [--out FILE] [--format p3|p6|png] [--binary]\n"
+                 "  without --format the suffix of FILE decides (.png: png, else p3); --binary is --format p6\n");
     return 2;
 }
 
@@ -30,7 +34,8 @@ int main(int argc, char** argv) {
     uint32_t scene_seed = 1;
     int spheres = 1000000;
     double aperture = 0;
-    bool binary = false;   // P6 instead of the reference's P3 text
+    std::string format;    // p3 (the reference's text), p6 or png
+    double view[7] = {13, 2, 3, 0, 0, 0, 20}, focus = 10;   // main.cpp:114-120
     for (int i = 1; i < argc; ++i) {
         std::string const a = argv[i];
         auto need = [&](char const* name) -> char const* {
@@ -47,9 +52,16 @@ int main(int argc, char** argv) {
         else if (a == "--device") opt.device = std::atoi(need("--device"));
         else if (a == "--aperture") aperture = std::atof(need("--aperture"));
         else if (a == "--out") out_path = need("--out");
-        else if (a == "--binary") binary = true;
+        else if (a == "--binary") format = "p6";
+        else if (a == "--format") format = need("--format");
+        else if (a == "--focus") focus = std::atof(need("--focus"));
+        else if (a == "--camera") {
+            if (std::sscanf(need("--camera"), "%lf,%lf,%lf,%lf,%lf,%lf,%lf", view, view + 1, view + 2, view + 3, view + 4, view + 5, view + 6) != 7) return usage();
+        }
         else return usage();
     }
+    if (format.empty()) format = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".png") == 0 ? "png" : "p3";
+    if (format != "p3" && format != "p6" && format != "png") return usage();
     try {
         std::mt19937 mt(scene_seed);
         recipe rc;
@@ -60,7 +72,7 @@ int main(int argc, char** argv) {
         else rc = recipe::load(scene);
         std::unique_ptr<object const> world = rc.instantiate(mt);
         // the camera of main.cpp:114-120
-        camera const cam{mt, vec3{13, 2, 3}, vec3{0, 0, 0}, vec3{0, 1, 0}, 20, double(opt.nx) / double(opt.ny), aperture, 10, 0, 1};
+        camera const cam{mt, vec3{view[0], view[1], view[2]}, vec3{view[3], view[4], view[5]}, vec3{0, 1, 0}, view[6], double(opt.nx) / double(opt.ny), aperture, focus, 0, 1};
         device_scene const dev(*world, opt.device);
         auto const start = std::chrono::steady_clock::now();
         frame const f = render(dev, cam, opt);
@@ -71,7 +83,9 @@ int main(int argc, char** argv) {
                      (double)f.stats.paths / (f.stats.kernel_ms * 1e3), (double)f.stats.rays / (double)f.stats.paths);
         std::FILE* out = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "wb");
         if (!out) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 1; }
-        if (binary) f.write_ppm_binary(out); else f.write_ppm(out);
+        if (format == "png") f.write_png(out);
+        else if (format == "p6") f.write_ppm_binary(out);
+        else f.write_ppm(out);
         if (out != stdout) std::fclose(out);
     } catch (std::exception const& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

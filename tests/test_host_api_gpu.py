@@ -25,6 +25,26 @@ def get(path, cols):
     return np.fromfile(path, dtype="<f8").reshape(-1, cols)
 
 
+def decode_png(data):
+    """8-bit RGB, filter 0 only -- what frame::write_png emits -- with every checksum verified."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        at += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype, comp, filt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, ctype, comp, filt, lace) == (8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert not rows[:, 0].any()
+    return rows[:, 1:].reshape(h, w, 3)
+
+
 @pytest.mark.parametrize("scene", ["mixed", "book2", "ties"])
 def test_object_hit_one_ray_at_a_time(tmp_path, scene):
     g = golden("trace_" + scene)
@@ -103,6 +123,9 @@ def test_frame_driver_writes_the_reference_ppm_and_its_binary_twin(tmp_path, rt)
     assert raw.startswith(header) and len(raw) == len(header) + 50 * 26 * 3
     p6 = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(26, 50, 3)
     assert np.array_equal(p3, p6)
+    # .png: the same bytes again, in a container any viewer opens
+    subprocess.run(common + ["--out", str(tmp_path / "c.png")], check=True, capture_output=True, timeout=300)
+    assert np.array_equal(decode_png((tmp_path / "c.png").read_bytes()), p6)
     # and they are the resolve of the library's own sums for the same seed
     cam15 = np.array(golden("frames")["camera"])
     cam15[10] = 50 / 26

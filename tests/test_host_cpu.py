@@ -117,3 +117,27 @@ def test_scene_description_is_validated(rt):
     rc = lib.rt_scene_create(ctypes.byref(d), 0, ctypes.byref(out))
     assert rc == 1 and b"earlier textures" in lib.rt_last_error()
     assert lib.rt_scene_create(None, 0, ctypes.byref(out)) == 1
+
+
+def test_image_writers_hold_the_reference_bytes(rt, tmp_path):
+    # supersampler::value, gamma2, convert and the P3 text of main.cpp:145-150 over the reference's
+    # own 256-sample frame; P6 and PNG must carry the same bytes
+    from test_host_api_gpu import decode_png
+    sums = golden("frames")["book2_spp256_seed1"]
+    ny, nx, _ = sums.shape
+    expect = (255.99 * np.sqrt(sums.astype(np.float64) / 256)).astype(np.int64)
+    rt.write_image(tmp_path / "a.ppm", sums, 256, "p3")
+    text = (tmp_path / "a.ppm").read_text().split()
+    assert text[:4] == ["P3", str(nx), str(ny), "255"]
+    assert np.array_equal(np.array(text[4:], dtype=np.int64).reshape(ny, nx, 3), expect)
+    rt.write_image(tmp_path / "b.ppm", sums, 256, "p6")
+    raw = (tmp_path / "b.ppm").read_bytes()
+    head = b"P6\n%d %d\n255\n" % (nx, ny)
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(ny, nx, 3), expect)
+    # a frame large enough for several stored deflate blocks
+    big = np.tile(sums, (4, 3, 1))
+    rt.write_image(tmp_path / "c.png", big, 256, "png")
+    assert np.array_equal(decode_png((tmp_path / "c.png").read_bytes()), np.tile(expect, (4, 3, 1)))
+    with pytest.raises(rt.RtError, match="unknown image format"):
+        rt.write_image(tmp_path / "d.gif", sums, 256, "gif")
