@@ -81,6 +81,7 @@ struct DScene {
     const uint8_t *perm;      // 3 x 256: x, y, z
     uint32_t n_items;
     uint32_t stack_depth;     // entries per lane
+    uint32_t recheck_all;     // test switch: treat every postponed box test as failed (see world_closest_voted)
 };
 
 struct DCamera {
@@ -463,13 +464,20 @@ __device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim
 // interval the reference would pass down: bvh_node.cpp:53) -- the walk above it was only
 // conservative; a leaf of static spheres is also skipped when its box starts beyond the best hit.
 // Then its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the next stack entry.
+//
+// `box_now` = false postpones the box test of a leaf of static spheres: its spheres are tried at once
+// and the caller tests the box of the winning leaf only (see world_closest_voted).
 template <bool SPILL>
-__device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv, bool box_now) {
     const int32_t ref = tv.cur;
     const int32_t leaf = ref & LEAF_INDEX_MASK;
     const char *rec = lleaves + (uint32_t)leaf * LLEAF_STRIDE;
-    double entry;
-    if (box_test_ordered(rec, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt)) {
+    bool reached = true;
+    if (box_now || !(ref & LEAF_SAFE)) {
+        double entry;
+        reached = box_test_ordered(rec, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt);
+    }
+    if (reached) {
         leaf_candidate_lds(rec + 48, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
         if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
     }
@@ -477,17 +485,32 @@ __device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx 
 }
 
 template <bool SPILL>
-__device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv) {
+__device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv, bool box_now) {
     const int32_t ref = tv.cur;
     const int32_t leaf = ref & LEAF_INDEX_MASK;
-    double bx[6], entry;
+    bool reached = true;
+    if (box_now || !(ref & LEAF_SAFE)) {
+        double bx[6], entry;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) bx[k] = leaves[leaf].box[k];
-    if (box_test(bx, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt)) {
+        for (int k = 0; k < 6; ++k) bx[k] = leaves[leaf].box[k];
+        reached = box_test(bx, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt);
+    }
+    if (reached) {
         leaf_candidate(prims, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
         if (ref & LEAF_TWO) leaf_candidate(prims, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
     }
     tv.cur = trav_pop<SPILL>(tv, st);
+}
+
+// the reference's test of the box of leaf `leaf` (as in the leaf steps), for a hit found with that test postponed
+template <bool LDS_TREE>
+__device__ __forceinline__ bool leaf_box_reached(const TreeView &tree, int32_t leaf, const RayCtx &r, double tmin, double tmax) {
+    double entry;
+    if (LDS_TREE) return box_test_ordered(tree.lleaves + (uint32_t)leaf * LLEAF_STRIDE, r, tmin, tmax, entry);
+    double bx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bx[k] = tree.leaves[leaf].box[k];
+    return box_test(bx, r, tmin, tmax, entry);
 }
 
 // Starts the walk of one world item.  The reference tests the root's box first (bvh_node.cpp:53);
@@ -517,7 +540,7 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
         const float tmax_above = above(closest);
         while (tv.cur != REF_NONE) {
             if (tv.cur >= 0) node_step<false>(sc.nodes, r, tmin_below, tmax_above, st, tv);
-            else leaf_step<false>(sc.leaves, sc.prims, r, tmin, closest, st, tv);
+            else leaf_step<false>(sc.leaves, sc.prims, r, tmin, closest, st, tv, true);
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }
@@ -538,7 +561,9 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 //
 // `work` grows by 1 per node iteration and by 3 per leaf iteration this lane took part in: the
 // lane that walked longest has counted what the wave executed, in units of roughly a node step.
-template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK>
+//
+// DEFER: the box tests of static-sphere leaves are postponed to the winning leaf (below).
+template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK, bool DEFER>
 __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
                                                     double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work,
                                                     LaneStats &stats) {
@@ -550,25 +575,42 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
         Trav tv;
         item_begin(sc, i, r, tmin, closest, tv);
         const float tmax_above = above(closest);
-        while (tv.cur != REF_NONE) {
-            const bool at_node = tv.cur >= 0;
-            const int n_node = __popcll(__ballot(at_node));
-            const int n_leaf = __popcll(__ballot(!at_node));
-            if (n_leaf >= LEAF_QUORUM || n_node == 0) {
-                stats.add(1, (uint32_t)n_leaf);
-                if (COUNT_WORK) work += 3;
-                if (!at_node) {
-                    if (LDS_TREE) leaf_step_lds<SPILL>(tree.lleaves, r, tmin, closest, st, tv);
-                    else leaf_step<SPILL>(tree.leaves, tree.prims, r, tmin, closest, st, tv);
-                }
-            } else {
-                stats.add(0, (uint32_t)n_node);
-                if (COUNT_WORK) work += 1;
-                if (at_node) {
-                    if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin_below, tmax_above, st, tv);
-                    else node_step<SPILL>(tree.nodes, r, tmin_below, tmax_above, st, tv);
+        // A static sphere lies inside its leaf's box, so a ray that hits the sphere passes the box
+        // test too, up to rounding in that test.  The first pass therefore tries the spheres of such
+        // leaves without the box test (exact = false): its candidates are the reference's and,
+        // at most, a few that the reference's box test would have kept out.  If the winner's own box
+        // test passes, it is the best of a superset that contains it: the reference's answer.  If it
+        // fails -- the ray grazes sphere and box within rounding -- the lane walks the item again
+        // with every box tested first (exact = true, wave-uniform).  Without DEFER the first pass
+        // is exact.
+        bool exact = !DEFER;
+        while (tv.cur != REF_NONE) {   // (a bare sphere has been tried by item_begin)
+            while (tv.cur != REF_NONE) {
+                const bool at_node = tv.cur >= 0;
+                const int n_node = __popcll(__ballot(at_node));
+                const int n_leaf = __popcll(__ballot(!at_node));
+                if (n_leaf >= LEAF_QUORUM || n_node == 0) {
+                    stats.add(1, (uint32_t)n_leaf);
+                    if (COUNT_WORK) work += 3;
+                    if (!at_node) {
+                        if (LDS_TREE) leaf_step_lds<SPILL>(tree.lleaves, r, tmin, closest, st, tv, exact);
+                        else leaf_step<SPILL>(tree.leaves, tree.prims, r, tmin, closest, st, tv, exact);
+                    }
+                } else {
+                    stats.add(0, (uint32_t)n_node);
+                    if (COUNT_WORK) work += 1;
+                    if (at_node) {
+                        if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin_below, tmax_above, st, tv);
+                        else node_step<SPILL>(tree.nodes, r, tmin_below, tmax_above, st, tv);
+                    }
                 }
             }
+            if (!DEFER || exact) break;
+            bool again = false;
+            if (tv.bp >= 0) again = sc.recheck_all || !leaf_box_reached<LDS_TREE>(tree, tv.bp >> 1, r, tmin, closest);
+            if (!__any(again)) break;
+            exact = true;
+            if (again) item_begin(sc, i, r, tmin, closest, tv);
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }

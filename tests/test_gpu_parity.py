@@ -470,6 +470,36 @@ def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stac
         w_768.close()
 
 
+@pytest.mark.parametrize("scene", ["book1", "book2", "stress4096", "mixed", "ties"])
+def test_postponed_leaf_box_tests_change_nothing(rt, orc, scene, monkeypatch):
+    # For leaves of static spheres the render kernel may try the spheres first and run the reference's
+    # test of the leaf's box (bvh_node.cpp:53 -> aabb.cpp:8-57) for the winning leaf only, walking again
+    # with every box tested up front if that one fails.  Off, on, on with every hit sent through the
+    # second walk, and the same on the large-tree shape: one frame, to the bit, and the oracle's.
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = 2.0
+    frames = []
+    for defer, recheck, lds_nodes in [("0", False, None), ("1", False, None), ("1", True, None), ("1", False, "9"), ("1", True, "9")]:
+        monkeypatch.setenv("RTIOW_DEFER_LEAF_BOXES", defer)
+        if recheck:
+            monkeypatch.setenv("RTIOW_RECHECK_ALL_LEAVES", "1")
+        if lds_nodes:
+            monkeypatch.setenv("RTIOW_RENDER_LDS_NODES", lds_nodes)
+            monkeypatch.setenv("RTIOW_RENDER_STACK_CAP", "2")
+        w = rt.World(recipe(scene))
+        for name in ("RTIOW_DEFER_LEAF_BOXES", "RTIOW_RECHECK_ALL_LEAVES", "RTIOW_RENDER_LDS_NODES", "RTIOW_RENDER_STACK_CAP"):
+            monkeypatch.delenv(name, raising=False)
+        try:
+            frames.append(w.render(rt.camera(cam15), 72, 36, 0, 5, 33))
+        finally:
+            w.close()
+    exp, counters = orc.Scene(recipe(scene)).render(cam15, 72, 36, 0, 5, 33, orc.ORC_RNG_STREAM)
+    for f, st in frames:
+        assert st.rays == counters.rays
+        assert np.array_equal(f, frames[0][0])
+    np.testing.assert_allclose(frames[0][0], exp, rtol=1e-11, atol=1e-13)
+
+
 def test_cost_ordered_tiles_render_the_same_frame(rt, worlds, monkeypatch):
     # Deep frames with many tiles get a costing pass and are rendered dearest tile first.  Which wave
     # renders which tile when must not change a bit of the image or the ray count.
