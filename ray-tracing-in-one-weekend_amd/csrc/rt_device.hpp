@@ -368,7 +368,13 @@ __device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy
     const float e_lo = __builtin_fmaf(__builtin_fabsf(e), -kWidenK, e) - r.widen;
     const float x_hi = __builtin_fmaf(__builtin_fabsf(x), kWidenK, x) + r.widen;
     entry = e_lo;
-    return !(__builtin_fminf(x_hi, tmax_above) < __builtin_fmaxf(e_lo, tmin_below));
+    // v_min_f32 / v_max_f32 as they are (the other operand when one is a NaN): the builtins would
+    // first re-canonicalise the two interval bounds in every step, against signalling NaNs that
+    // nothing here produces
+    float x_in, e_in;
+    asm("v_min_f32 %0, %1, %2" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above));
+    asm("v_max_f32 %0, %1, %2" : "=v"(e_in) : "v"(e_lo), "v"(tmin_below));
+    return !(x_in < e_in);
 }
 
 // One node read from device memory: test both child boxes, continue with the nearer, push the
@@ -412,25 +418,54 @@ struct TreeView {
     int32_t n_lnodes;
 };
 
-// node_step on the LDS copy; the planes are read in the order the ray meets them (the swap of
-// aabb.cpp:16-18 becomes a choice of address, free when every lane reads its own node anyway)
-template <bool SPILL>
-__device__ __forceinline__ void node_step_lds(const char *lnodes, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
-    const char *nd = lnodes + (uint32_t)tv.cur * LNODE_STRIDE;
+// Where a ray finds the planes of an LDS node record, in the order it meets them (the swap of
+// aabb.cpp:16-18 becomes a choice of address, free when every lane reads its own node anyway):
+// the addresses of child 0's near and far plane per axis in record 0.  Child 1's planes lie 24
+// bytes further, so each pair is one two-address LDS read off "plane address + record offset".
+//
+// They are kept as 32-bit LDS addresses that the compiler cannot see into: it would otherwise split
+// the constant part of the tree's position off each of them, to fold it into the read's offset
+// field, find that a two-address read has no room for it, and add it back in every step.
+struct PlaneAddr {
+    uint32_t xn, xf, yn, yf, zn, zf;
+};
+typedef __attribute__((address_space(3))) const char lds_cchar;
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ uint32_t lds_address(const char *p) {
+    uint32_t a = (uint32_t)(uintptr_t)(lds_cchar *)p;
+    asm("" : "+v"(a));
+    return a;
+}
+__device__ __forceinline__ float lds_float(uint32_t address) { return *(lds_cfloat *)(uintptr_t)address; }
+__device__ __forceinline__ PlaneAddr plane_addresses(const char *lnodes, const RayCtx &r) {
+    const uint32_t ox = r.nx8 >> 1, oy = r.ny8 >> 1, oz = r.nz8 >> 1;   // 0 or 4: byte offset of the nearer plane in a pair
+    PlaneAddr a = {lds_address(lnodes + ox), lds_address(lnodes + (ox ^ 4u)), lds_address(lnodes + 8 + oy),
+                   lds_address(lnodes + 8 + (oy ^ 4u)), lds_address(lnodes + 16 + oz), lds_address(lnodes + 16 + (oz ^ 4u))};
+    return a;
+}
+
+// node_step on the LDS copy.  PREMUL: node references are byte offsets of the records already
+// (trees that live in LDS whole), not indices.
+template <bool SPILL, bool PREMUL>
+__device__ __forceinline__ void node_step_lds(const char *lnodes, const PlaneAddr &pa, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
+    const uint32_t off = PREMUL ? (uint32_t)tv.cur : (uint32_t)tv.cur * LNODE_STRIDE;
+    const char *nd = lnodes + off;
     const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 48), c1 = *reinterpret_cast<const int32_t *>(nd + 52);
     const uint32_t flags = *reinterpret_cast<const uint32_t *>(nd + 56);
-    const uint32_t ox = r.nx8 >> 1, oy = r.ny8 >> 1, oz = r.nz8 >> 1;   // 0 or 4: byte offset of the nearer plane in a pair
     float e[2];
     bool h[2];
     const bool none = tv.bp < 0;
+    float pl[2][6];   // all twelve planes first
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const char *b = nd + 24 * c;
-        h[c] = node_test(*reinterpret_cast<const float *>(b + ox), *reinterpret_cast<const float *>(b + (ox ^ 4u)),
-                         *reinterpret_cast<const float *>(b + 8 + oy), *reinterpret_cast<const float *>(b + 8 + (oy ^ 4u)),
-                         *reinterpret_cast<const float *>(b + 16 + oz), *reinterpret_cast<const float *>(b + 16 + (oz ^ 4u)),
-                         r, tmin_below, tmax_above, e[c]);
-        h[c] = h[c] && (!(flags & (c ? NF_SAFE1 : NF_SAFE0)) || none || !(e[c] > tv.bt_above));
+        pl[c][0] = lds_float(pa.xn + off + 24 * c); pl[c][1] = lds_float(pa.xf + off + 24 * c);
+        pl[c][2] = lds_float(pa.yn + off + 24 * c); pl[c][3] = lds_float(pa.yf + off + 24 * c);
+        pl[c][4] = lds_float(pa.zn + off + 24 * c); pl[c][5] = lds_float(pa.zf + off + 24 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        h[c] = node_test(pl[c][0], pl[c][1], pl[c][2], pl[c][3], pl[c][4], pl[c][5], r, tmin_below, tmax_above, e[c]);
+        h[c] = h[c] & (!(flags & (c ? NF_SAFE1 : NF_SAFE0)) | none | !(e[c] > tv.bt_above));
     }
     node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
 }
@@ -568,12 +603,14 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
                                                     double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work,
                                                     LaneStats &stats) {
     constexpr bool SPILL = !LDS_TREE;
+    const PlaneAddr pa = plane_addresses(tree.lnodes, r);
     const float tmin_below = below(tmin);
     double closest = tmax;
     int found = -1;
     for (uint32_t i = 0; i < sc.n_items; ++i) {
         Trav tv;
         item_begin(sc, i, r, tmin, closest, tv);
+        if (LDS_TREE && tv.cur >= 0) tv.cur *= (int32_t)LNODE_STRIDE;   // node references are record offsets there
         const float tmax_above = above(closest);
         // A static sphere lies inside its leaf's box, so a ray that hits the sphere passes the box
         // test too, up to rounding in that test.  The first pass therefore tries the spheres of such
@@ -600,7 +637,8 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
                     stats.add(0, (uint32_t)n_node);
                     if (COUNT_WORK) work += 1;
                     if (at_node) {
-                        if (LDS_TREE || tv.cur < tree.n_lnodes) node_step_lds<SPILL>(tree.lnodes, r, tmin_below, tmax_above, st, tv);
+                        if (LDS_TREE) node_step_lds<SPILL, true>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
+                        else if (tv.cur < tree.n_lnodes) node_step_lds<SPILL, false>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
                         else node_step<SPILL>(tree.nodes, r, tmin_below, tmax_above, st, tv);
                     }
                 }
@@ -610,7 +648,10 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
             if (tv.bp >= 0) again = sc.recheck_all || !leaf_box_reached<LDS_TREE>(tree, tv.bp >> 1, r, tmin, closest);
             if (!__any(again)) break;
             exact = true;
-            if (again) item_begin(sc, i, r, tmin, closest, tv);
+            if (again) {
+                item_begin(sc, i, r, tmin, closest, tv);
+                if (LDS_TREE && tv.cur >= 0) tv.cur *= (int32_t)LNODE_STRIDE;
+            }
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }

@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
         char *lnodes = ltree, *lleaves = ltree + (((size_t)n_lnodes * LNODE_STRIDE + 7) & ~(size_t)7);
         for (uint32_t i = tid; i < n_lnodes * 15u; i += kRenderBlock) {   // 15 words of a node record are copied
             const uint32_t n = i / 15u, w = i % 15u;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.nodes + n);
-            reinterpret_cast<uint32_t *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = src[w];
+            uint32_t v = reinterpret_cast<const uint32_t *>(sc.nodes + n)[w];
+            // a tree that is in LDS whole refers to its nodes by the byte offset of their records
+            if (LDS_TREE && (w == 12u || w == 13u) && (int32_t)v >= 0) v *= LNODE_STRIDE;
+            reinterpret_cast<uint32_t *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = v;
         }
         for (uint32_t i = tid; i < n_lleaves * 28u; i += kRenderBlock) {   // 6 doubles of the box, 11 of each sphere record
             const uint32_t n = i / 28u, w = i % 28u;
