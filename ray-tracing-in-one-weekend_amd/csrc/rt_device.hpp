@@ -309,7 +309,7 @@ struct Trav {
     int32_t sp;      // stack entries in use
     double bt;       // best hit of the item being walked
     int32_t bp;      // its primitive (device order), -1 = none
-    float bt_above;  // bt rounded up, for the conservative node test
+    float bt_above;  // bt rounded up, for the conservative node test; +inf while there is no hit
 };
 
 // A lane's traversal stack.  Entry k lives in LDS at lds[k * stride] (the block's lanes are
@@ -358,8 +358,10 @@ __device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, boo
 // exit bound raised by the rounding error bound of make_ctx's constants, a NaN plane (0 * inf)
 // drops out of max3/min3 as it leaves the reference's bounds unchanged, and NaN bounds pass.
 // `entry` is a lower bound of the exact entry distance.
+// `limit` is a second upper bound (the best hit so far, for children that may be skipped behind it;
+// +inf for none): it rides along in the three-operand minimum for free.
 __device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy, float nz, float fz, const RayCtx &r,
-                                          float tmin_below, float tmax_above, float &entry) {
+                                          float tmin_below, float tmax_above, float limit, float &entry) {
     const float tnx = __builtin_fmaf(nx, r.ixf, r.cxf), tfx = __builtin_fmaf(fx, r.ixf, r.cxf);
     const float tny = __builtin_fmaf(ny, r.iyf, r.cyf), tfy = __builtin_fmaf(fy, r.iyf, r.cyf);
     const float tnz = __builtin_fmaf(nz, r.izf, r.czf), tfz = __builtin_fmaf(fz, r.izf, r.czf);
@@ -368,33 +370,34 @@ __device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy
     const float e_lo = __builtin_fmaf(__builtin_fabsf(e), -kWidenK, e) - r.widen;
     const float x_hi = __builtin_fmaf(__builtin_fabsf(x), kWidenK, x) + r.widen;
     entry = e_lo;
-    // v_min_f32 / v_max_f32 as they are (the other operand when one is a NaN): the builtins would
+    // v_min3_f32 / v_max_f32 as they are (NaN operands drop out): the builtins would
     // first re-canonicalise the two interval bounds in every step, against signalling NaNs that
     // nothing here produces
     float x_in, e_in;
-    asm("v_min_f32 %0, %1, %2" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above), "v"(limit));
     asm("v_max_f32 %0, %1, %2" : "=v"(e_in) : "v"(e_lo), "v"(tmin_below));
     return !(x_in < e_in);
 }
 
 // One node read from device memory: test both child boxes, continue with the nearer, push the
-// farther.  A SAFE child is also skipped when it starts beyond the best hit so far.
-template <bool SPILL>
+// farther.  A SAFE child is also skipped when it starts beyond the best hit so far (tv.bt_above, +inf
+// while there is none).
+// ALL_SAFE: every child may (the scene has no moving sphere), so the flags are not looked at.
+template <bool SPILL, bool ALL_SAFE = false>
 __device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
     const DNode *nd = nodes + tv.cur;
-    const uint32_t flags = nd->flags;
+    const uint32_t flags = ALL_SAFE ? 0u : nd->flags;
     const int32_t c0 = nd->child[0], c1 = nd->child[1];
     float b[2][6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { b[0][k] = nd->bx[0][k]; b[1][k] = nd->bx[1][k]; }
     float e[2];
     bool h[2];
-    const bool none = tv.bp < 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+        const float limit = ALL_SAFE || (flags & (c ? NF_SAFE1 : NF_SAFE0)) ? tv.bt_above : HUGE_VALF;
         h[c] = node_test(r.nx8 ? b[c][1] : b[c][0], r.nx8 ? b[c][0] : b[c][1], r.ny8 ? b[c][3] : b[c][2], r.ny8 ? b[c][2] : b[c][3],
-                         r.nz8 ? b[c][5] : b[c][4], r.nz8 ? b[c][4] : b[c][5], r, tmin_below, tmax_above, e[c]);
-        h[c] = h[c] && (!(flags & (c ? NF_SAFE1 : NF_SAFE0)) || none || !(e[c] > tv.bt_above));
+                         r.nz8 ? b[c][5] : b[c][4], r.nz8 ? b[c][4] : b[c][5], r, tmin_below, tmax_above, limit, e[c]);
     }
     node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
 }
@@ -446,15 +449,14 @@ __device__ __forceinline__ PlaneAddr plane_addresses(const char *lnodes, const R
 
 // node_step on the LDS copy.  PREMUL: node references are byte offsets of the records already
 // (trees that live in LDS whole), not indices.
-template <bool SPILL, bool PREMUL>
+template <bool SPILL, bool PREMUL, bool ALL_SAFE>
 __device__ __forceinline__ void node_step_lds(const char *lnodes, const PlaneAddr &pa, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
     const uint32_t off = PREMUL ? (uint32_t)tv.cur : (uint32_t)tv.cur * LNODE_STRIDE;
     const char *nd = lnodes + off;
     const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 48), c1 = *reinterpret_cast<const int32_t *>(nd + 52);
-    const uint32_t flags = *reinterpret_cast<const uint32_t *>(nd + 56);
+    const uint32_t flags = ALL_SAFE ? 0u : *reinterpret_cast<const uint32_t *>(nd + 56);
     float e[2];
     bool h[2];
-    const bool none = tv.bp < 0;
     float pl[2][6];   // all twelve planes first
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -464,8 +466,8 @@ __device__ __forceinline__ void node_step_lds(const char *lnodes, const PlaneAdd
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        h[c] = node_test(pl[c][0], pl[c][1], pl[c][2], pl[c][3], pl[c][4], pl[c][5], r, tmin_below, tmax_above, e[c]);
-        h[c] = h[c] & (!(flags & (c ? NF_SAFE1 : NF_SAFE0)) | none | !(e[c] > tv.bt_above));
+        const float limit = ALL_SAFE || (flags & (c ? NF_SAFE1 : NF_SAFE0)) ? tv.bt_above : HUGE_VALF;
+        h[c] = node_test(pl[c][0], pl[c][1], pl[c][2], pl[c][3], pl[c][4], pl[c][5], r, tmin_below, tmax_above, limit, e[c]);
     }
     node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
 }
@@ -554,7 +556,7 @@ __device__ __forceinline__ bool leaf_box_reached(const TreeView &tree, int32_t l
 // (has_box = 0) is tried on the spot, as object_list.cpp:18 does, and the walk stays empty.
 __device__ __forceinline__ void item_begin(const DScene &sc, uint32_t item, const RayCtx &r, double tmin, double tmax, Trav &tv) {
     const DItem *it = sc.items + item;
-    tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.bt_above = 0; tv.cur = REF_NONE;
+    tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.bt_above = HUGE_VALF; tv.cur = REF_NONE;
     const int32_t ref = it->ref;
     if (!it->has_box) leaf_candidate(sc.prims, 2 * (ref & LEAF_INDEX_MASK), ref & LEAF_MOVING0, r, tmin, tmax, tv);
     else tv.cur = ref;
@@ -597,7 +599,8 @@ __device__ __forceinline__ bool world_closest(const DScene &sc, const RayCtx &r,
 // `work` grows by 1 per node iteration and by 3 per leaf iteration this lane took part in: the
 // lane that walked longest has counted what the wave executed, in units of roughly a node step.
 //
-// DEFER: the box tests of static-sphere leaves are postponed to the winning leaf (below).
+// DEFER: for scenes without moving spheres.  The box tests of the leaves are postponed to the winning
+// leaf (below), and every subtree may be skipped behind the best hit without looking at flags.
 template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK, bool DEFER>
 __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin,
                                                     double tmax, const LaneStack &st, double &t_out, int &prim_out, uint32_t &work,
@@ -637,9 +640,9 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
                     stats.add(0, (uint32_t)n_node);
                     if (COUNT_WORK) work += 1;
                     if (at_node) {
-                        if (LDS_TREE) node_step_lds<SPILL, true>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
-                        else if (tv.cur < tree.n_lnodes) node_step_lds<SPILL, false>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
-                        else node_step<SPILL>(tree.nodes, r, tmin_below, tmax_above, st, tv);
+                        if (LDS_TREE) node_step_lds<SPILL, true, DEFER>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
+                        else if (tv.cur < tree.n_lnodes) node_step_lds<SPILL, false, DEFER>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
+                        else node_step<SPILL, DEFER>(tree.nodes, r, tmin_below, tmax_above, st, tv);
                     }
                 }
             }

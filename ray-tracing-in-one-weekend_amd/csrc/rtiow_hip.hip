@@ -877,14 +877,13 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = stack_depth;
-    // Postponing the box tests of static-sphere leaves to the winning leaf pays when a wave's leaf
-    // step rarely meets a moving sphere: at most 1 leaf in 100 (measured: +3.3 % with none, -1.2 %
-    // with 80 in 100).  RTIOW_DEFER_LEAF_BOXES=0/1 overrides; RTIOW_RECHECK_ALL_LEAVES makes every
-    // hit take the second, exact walk (both for tests).
+    // Scenes without a moving sphere run the kernel variant that postpones the leaves' box tests to
+    // the winning leaf and skips behind the best hit without consulting flags (k_render's DEFER).
+    // RTIOW_DEFER_LEAF_BOXES=0 keeps the general variant; RTIOW_RECHECK_ALL_LEAVES makes every hit
+    // take the second, exact walk (both for tests).
     {
         const char *defer_env = getenv("RTIOW_DEFER_LEAF_BOXES");
-        const bool defer = defer_env ? atoi(defer_env) != 0 : !fl.nodes.empty() && fl.n_moving_leaves * 100 <= fl.leaf_boxes.size();
-        s->render_defer = defer;
+        s->render_defer = !fl.nodes.empty() && fl.n_moving_leaves == 0 && !(defer_env && atoi(defer_env) == 0);
         s->d.recheck_all = getenv("RTIOW_RECHECK_ALL_LEAVES") ? 1u : 0u;
     }
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);

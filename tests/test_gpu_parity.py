@@ -472,10 +472,11 @@ def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stac
 
 @pytest.mark.parametrize("scene", ["book1", "book2", "stress4096", "mixed", "ties"])
 def test_postponed_leaf_box_tests_change_nothing(rt, orc, scene, monkeypatch):
-    # For leaves of static spheres the render kernel may try the spheres first and run the reference's
-    # test of the leaf's box (bvh_node.cpp:53 -> aabb.cpp:8-57) for the winning leaf only, walking again
-    # with every box tested up front if that one fails.  Off, on, on with every hit sent through the
-    # second walk, and the same on the large-tree shape: one frame, to the bit, and the oracle's.
+    # In scenes without moving spheres the render kernel tries a leaf's spheres first and runs the
+    # reference's test of the leaf's box (bvh_node.cpp:53 -> aabb.cpp:8-57) for the winning leaf only,
+    # walking again with every box tested up front if that one fails.  Off, on, on with every hit sent
+    # through the second walk, and the same on the large-tree shape: one frame, to the bit, and the
+    # oracle's.  (Scenes with moving spheres always run the general kernel: the switch does nothing.)
     cam15 = np.array(golden("frames")["camera"])
     cam15[10] = 2.0
     frames = []
