@@ -37,9 +37,22 @@ static_assert(sizeof(DNode) == 64, "DNode is one 64-byte line");
 
 struct DLeaf { double box[6]; };
 
-// a plane of an inner box in single precision: not above (below) the double it stands for
-__host__ __device__ inline float plane_down(double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -HUGE_VALF); return f; }
-__host__ __device__ inline float plane_up(double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, HUGE_VALF); return f; }   // the reference's box of the leaf: min x, max x, min y, max y, min z, max z
+// A plane of an inner box in single precision: moved outward by 2^-22 of its magnitude (the part of
+// the conservative test's error bound that is proportional to plane / d, see make_ctx), then
+// rounded outward.
+constexpr double kPlaneWiden = 0x1p-22;
+__host__ __device__ inline float plane_down(double v) {
+    v -= kPlaneWiden * (v < 0 ? -v : v);
+    float f = (float)v;
+    if ((double)f > v) f = nextafterf(f, -HUGE_VALF);
+    return f;
+}
+__host__ __device__ inline float plane_up(double v) {
+    v += kPlaneWiden * (v < 0 ? -v : v);
+    float f = (float)v;
+    if ((double)f < v) f = nextafterf(f, HUGE_VALF);
+    return f;
+}
 
 // Every primitive under a SAFE child stays inside the child's box (static spheres), so
 // the descent may be skipped once the box starts beyond the best hit.  A moving sphere
@@ -113,16 +126,20 @@ struct RayCtx {
     // the plane the ray meets first inside a (min, max) pair: 0 or 8.
     uint32_t nx8, ny8, nz8;
     double a;            // d.d (sphere.cpp:14)
-    // single-precision constants of the conservative node test: t = plane * i + c with
-    // i = 1/d and c = -o/d per axis, and the widening K * max|c| (see node_test)
-    float ixf, iyf, izf, cxf, cyf, czf, widen;
+    // single-precision constants of the conservative node test: t = plane * i + c with i = 1/d and
+    // c = -o/d per axis, c lowered for the planes the ray meets first and raised for the others
+    // (see node_test)
+    float ixf, iyf, izf, cnx, cny, cnz, cfx, cfy, cfz;
 };
 
-// The conservative test computes t = fma(plane, i, c) in single precision for a plane that was
-// rounded outward.  Against the exact (plane - o) / d: i and c carry a relative rounding error
-// of 2^-24 each and the fma another, so |t - exact| <= 2^-22 (|t| + |c|); the test widens by
-// K (|t| + max|c|) with K = 2^-21, twice that.
-constexpr float kWidenK = 0x1p-21f;
+// The conservative test computes t = fma(plane, i, c) in single precision.  Against the exact
+// (plane - o) / d = plane / d + C: i carries a relative rounding error of 2^-24, c two of them (its
+// own and that of the shift below), the fma another on the sum, so
+// |t - exact| <= 2^-23 |plane / d| + 1.5 * 2^-23 |C| (1 + 2^-21).  Both parts are paid in advance:
+// the stored planes lie outward by 2^-22 |plane| (plane_down / plane_up), and the constant is
+// lowered (entry side) or raised (exit side) by K * sum|c| with K = 2^-22 -- a sum, so that one
+// amount serves all three axes.  tools/conservative_check.hip hunts for counter-examples.
+constexpr float kWidenK = 0x1p-22f;
 // a bound rounded away from the interval: x lowered (raised) by at least its conversion error
 __device__ __forceinline__ float below(double x) { const float f = (float)x; return f - __builtin_fabsf(f) * 0x1p-22f; }
 __device__ __forceinline__ float above(double x) { const float f = (float)x; return f + __builtin_fabsf(f) * 0x1p-22f; }
@@ -135,15 +152,20 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
     c.nx8 = c.ix < 0 ? 8u : 0u; c.ny8 = c.iy < 0 ? 8u : 0u; c.nz8 = c.iz < 0 ? 8u : 0u;
     c.a = vdot(r.d, r.d);
     c.ixf = (float)c.ix; c.iyf = (float)c.iy; c.izf = (float)c.iz;
-    c.cxf = (float)-(r.o.x * c.ix); c.cyf = (float)-(r.o.y * c.iy); c.czf = (float)-(r.o.z * c.iz);
+    const float cx = (float)-(r.o.x * c.ix), cy = (float)-(r.o.y * c.iy), cz = (float)-(r.o.z * c.iz);
     // A zero, huge or NaN direction component makes an infinite or NaN constant; the test then
-    // yields infinite or NaN bounds, and those pass: such rays simply visit more of the tree.
-    // The error bound is relative, which single precision only honours away from its subnormal
-    // range: the floor 2^-100 covers products and constants that underflow, and a reciprocal
-    // below 2^-100 (a direction component beyond 2^100) widens without limit.
-    // (the sum bounds the largest |c| and, unlike a maximum, hands a NaN on)
+    // yields infinite or NaN bounds for that axis, and those drop out or pass: such rays simply
+    // visit more of the tree.  The error bound is relative, which single precision only honours
+    // away from its subnormal range: the floor 2^-100 covers products and constants that underflow,
+    // and a reciprocal below 2^-100 (a direction component beyond 2^100) or one that overflows single
+    // precision widens without limit.
+    // (the sums bound every |c| and |i| and, unlike a maximum, hand a NaN on)
     const float smallest = __builtin_fminf(__builtin_fminf(__builtin_fabsf(c.ixf), __builtin_fabsf(c.iyf)), __builtin_fabsf(c.izf));
-    c.widen = kWidenK * (__builtin_fabsf(c.cxf) + __builtin_fabsf(c.cyf) + __builtin_fabsf(c.czf)) + (smallest >= 0x1p-100f ? 0x1p-100f : HUGE_VALF);
+    const float all = __builtin_fabsf(c.ixf) + __builtin_fabsf(c.iyf) + __builtin_fabsf(c.izf);
+    const float widen = kWidenK * (__builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz)) +
+                        (smallest >= 0x1p-100f && all < HUGE_VALF ? 0x1p-100f : HUGE_VALF);
+    c.cnx = cx - widen; c.cny = cy - widen; c.cnz = cz - widen;
+    c.cfx = cx + widen; c.cfy = cy + widen; c.cfz = cz + widen;
     return c;
 }
 
@@ -353,22 +375,20 @@ __device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, boo
 }
 
 // The conservative slab test of one child box.  n* are the planes the ray meets first on each
-// axis, f* the ones it meets last (outward-rounded single precision).  Returns false only when
-// the exact test of aabb.cpp:8-57 on the box inside would fail: the entry bound is lowered and the
-// exit bound raised by the rounding error bound of make_ctx's constants, a NaN plane (0 * inf)
+// axis, f* the ones it meets last (single precision, moved and rounded outward).  Returns false
+// only when the exact test of aabb.cpp:8-57 on the box inside would fail: the planes and the
+// constants carry the rounding error bound in advance (see make_ctx), a NaN slab value (0 * inf)
 // drops out of max3/min3 as it leaves the reference's bounds unchanged, and NaN bounds pass.
 // `entry` is a lower bound of the exact entry distance.
 // `limit` is a second upper bound (the best hit so far, for children that may be skipped behind it;
 // +inf for none): it rides along in the three-operand minimum for free.
 __device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy, float nz, float fz, const RayCtx &r,
                                           float tmin_below, float tmax_above, float limit, float &entry) {
-    const float tnx = __builtin_fmaf(nx, r.ixf, r.cxf), tfx = __builtin_fmaf(fx, r.ixf, r.cxf);
-    const float tny = __builtin_fmaf(ny, r.iyf, r.cyf), tfy = __builtin_fmaf(fy, r.iyf, r.cyf);
-    const float tnz = __builtin_fmaf(nz, r.izf, r.czf), tfz = __builtin_fmaf(fz, r.izf, r.czf);
-    const float e = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-    const float x = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-    const float e_lo = __builtin_fmaf(__builtin_fabsf(e), -kWidenK, e) - r.widen;
-    const float x_hi = __builtin_fmaf(__builtin_fabsf(x), kWidenK, x) + r.widen;
+    const float tnx = __builtin_fmaf(nx, r.ixf, r.cnx), tfx = __builtin_fmaf(fx, r.ixf, r.cfx);
+    const float tny = __builtin_fmaf(ny, r.iyf, r.cny), tfy = __builtin_fmaf(fy, r.iyf, r.cfy);
+    const float tnz = __builtin_fmaf(nz, r.izf, r.cnz), tfz = __builtin_fmaf(fz, r.izf, r.cfz);
+    const float e_lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float x_hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
     entry = e_lo;
     // v_min3_f32 / v_max_f32 as they are (NaN operands drop out): the builtins would
     // first re-canonicalise the two interval bounds in every step, against signalling NaNs that

@@ -85,8 +85,10 @@ __global__ void k_check(unsigned long long base, unsigned long long n, unsigned 
     atomicAdd(counts + 0, 1ull);
     if (exact) atomicAdd(counts + 1, 1ull);
     if (cons && !exact) atomicAdd(counts + 2, 1ull);
-    // the entry bound feeds "skip when the box starts beyond the best hit": it must not exceed the exact entry
-    const bool bad = exact && (!cons || (double)e32 > entry);
+    // the entry bound feeds "skip when the box starts beyond the best hit", a comparison with another
+    // float: no float below it may reach the exact entry (+inf is a sound bound for an entry beyond
+    // the largest float)
+    const bool bad = exact && (!cons || ((double)e32 > entry && !(e32 == HUGE_VALF && entry > (double)FLT_MAX)));
     if (bad && si < 5 && mode != 4) atomicAdd(counts + 4, 1ull);
     if (bad && atomicAdd(counts + 3, 1ull) == 0) {
         for (int k = 0; k < 6; ++k) example[k] = box[k];
