@@ -524,37 +524,40 @@ __device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim
 //
 // `box_now` = false postpones the box test of a leaf of static spheres: its spheres are tried at once
 // and the caller tests the box of the winning leaf only (see world_closest_voted).
-template <bool SPILL>
+// ALL_STATIC: the scene has no moving sphere, so every leaf is SAFE and the flags are not looked at.
+template <bool SPILL, bool ALL_STATIC = false>
 __device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv, bool box_now) {
     const int32_t ref = tv.cur;
     const int32_t leaf = ref & LEAF_INDEX_MASK;
     const char *rec = lleaves + (uint32_t)leaf * LLEAF_STRIDE;
+    const bool safe = ALL_STATIC || (ref & LEAF_SAFE);
     bool reached = true;
-    if (box_now || !(ref & LEAF_SAFE)) {
+    if (box_now || !safe) {
         double entry;
-        reached = box_test_ordered(rec, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt);
+        reached = box_test_ordered(rec, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
     }
     if (reached) {
-        leaf_candidate_lds(rec + 48, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
-        if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+        leaf_candidate_lds(rec + 48, 2 * leaf, !ALL_STATIC && (ref & LEAF_MOVING0), r, tmin, tmax, tv);
+        if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, !ALL_STATIC && (ref & LEAF_MOVING1), r, tmin, tmax, tv);
     }
     tv.cur = trav_pop<SPILL>(tv, st);
 }
 
-template <bool SPILL>
+template <bool SPILL, bool ALL_STATIC = false>
 __device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prims, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv, bool box_now) {
     const int32_t ref = tv.cur;
     const int32_t leaf = ref & LEAF_INDEX_MASK;
+    const bool safe = ALL_STATIC || (ref & LEAF_SAFE);
     bool reached = true;
-    if (box_now || !(ref & LEAF_SAFE)) {
+    if (box_now || !safe) {
         double bx[6], entry;
 #pragma unroll
         for (int k = 0; k < 6; ++k) bx[k] = leaves[leaf].box[k];
-        reached = box_test(bx, r, tmin, tmax, entry) && (!(ref & LEAF_SAFE) || tv.bp < 0 || entry <= tv.bt);
+        reached = box_test(bx, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
     }
     if (reached) {
-        leaf_candidate(prims, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
-        if (ref & LEAF_TWO) leaf_candidate(prims, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+        leaf_candidate(prims, 2 * leaf, !ALL_STATIC && (ref & LEAF_MOVING0), r, tmin, tmax, tv);
+        if (ref & LEAF_TWO) leaf_candidate(prims, 2 * leaf + 1, !ALL_STATIC && (ref & LEAF_MOVING1), r, tmin, tmax, tv);
     }
     tv.cur = trav_pop<SPILL>(tv, st);
 }
@@ -653,8 +656,8 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
                     stats.add(1, (uint32_t)n_leaf);
                     if (COUNT_WORK) work += 3;
                     if (!at_node) {
-                        if (LDS_TREE) leaf_step_lds<SPILL>(tree.lleaves, r, tmin, closest, st, tv, exact);
-                        else leaf_step<SPILL>(tree.leaves, tree.prims, r, tmin, closest, st, tv, exact);
+                        if (LDS_TREE) leaf_step_lds<SPILL, DEFER>(tree.lleaves, r, tmin, closest, st, tv, exact);
+                        else leaf_step<SPILL, DEFER>(tree.leaves, tree.prims, r, tmin, closest, st, tv, exact);
                     }
                 } else {
                     stats.add(0, (uint32_t)n_node);
