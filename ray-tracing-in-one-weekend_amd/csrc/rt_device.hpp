@@ -284,10 +284,11 @@ __device__ __forceinline__ v3 prim_centre(const DPrim *p, uint32_t moving, doubl
 
 // sphere.cpp:9-45, moving_sphere.cpp:13-49: the root the reference accepts in
 // (tmin, tmax), nearer root first
-__device__ __forceinline__ bool sphere_root(v3 c, double radius, const RayCtx &r, double tmin, double tmax, double &t_out) {
+// (radius2 = radius * radius, as sphere.cpp:16 forms it)
+__device__ __forceinline__ bool sphere_root(v3 c, double radius2, const RayCtx &r, double tmin, double tmax, double &t_out) {
     v3 oc = vsub(r.o, c);
     double b = vdot(oc, r.d);
-    double cc = vdot(oc, oc) - radius * radius;
+    double cc = vdot(oc, oc) - radius2;
     double disc = b * b - r.a * cc;
     bool hit = false;
     if (disc > 0) {
@@ -426,7 +427,7 @@ __device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, f
 // same field of different records spread over the 64 banks: 17 dwords for the 32-bit reads
 // of a node, 58 dwords (a factor 2, which a 64-bit read covers) for a leaf.
 constexpr uint32_t LNODE_STRIDE = 68;    // bx[2][6] floats | child[2] | flags
-constexpr uint32_t LPRIM_BYTES = 88;     // c0[3] r dc[3] t0 t1 | mat kind orig pad
+constexpr uint32_t LPRIM_BYTES = 88;     // c0[3] r*r dc[3] t0 t1 | mat kind orig pad
 constexpr uint32_t LLEAF_STRIDE = 232;   // box[6] doubles | sphere | sphere | pad
 
 // Where a walk finds the tree.  The block's LDS holds the first n_lnodes nodes (all of them
@@ -500,21 +501,21 @@ __device__ __forceinline__ void leaf_candidate(const DPrim *prims, int32_t prim,
                                                double tmin, double tmax, Trav &tv) {
     const DPrim *p = prims + prim;
     double t;
-    if (sphere_root(prim_centre(p, moving, r.time), p->r, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
+    if (sphere_root(prim_centre(p, moving, r.time), p->r * p->r, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
 }
 
 __device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim, bool moving, const RayCtx &r,
                                                    double tmin, double tmax, Trav &tv) {
     const double *p = reinterpret_cast<const double *>(rec);
     v3 c = mk(p[0], p[1], p[2]);
-    const double radius = p[3];
+    const double radius2 = p[3];   // the LDS copy holds the square
     if (moving) {
         const uint32_t kind = *reinterpret_cast<const uint32_t *>(rec + 76);
         const double s = (kind == PK_MOVING_UNIT) ? r.time : (r.time - p[7]) / (p[8] - p[7]);
         c = vadd(c, vmul(mk(p[4], p[5], p[6]), s));
     }
     double t;
-    if (sphere_root(c, radius, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
+    if (sphere_root(c, radius2, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
 }
 
 // One leaf.  First the reference's own test of the leaf's box (aabb.cpp:8-57, in double, with the

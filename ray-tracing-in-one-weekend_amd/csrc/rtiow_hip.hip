@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
             const uint32_t n = i / 28u, w = i % 28u;
             double v;
             if (w < 6u) v = sc.leaves[n].box[w];
-            else v = reinterpret_cast<const double *>(sc.prims + 2u * n + (w - 6u) / 11u)[(w - 6u) % 11u];
+            else {
+                v = reinterpret_cast<const double *>(sc.prims + 2u * n + (w - 6u) / 11u)[(w - 6u) % 11u];
+                if ((w - 6u) % 11u == 3u) v = v * v;   // the sphere test wants radius * radius (sphere.cpp:16)
+            }
             reinterpret_cast<double *>(lleaves + (size_t)n * LLEAF_STRIDE)[w] = v;
         }
         tree.lnodes = lnodes; tree.lleaves = lleaves;
