@@ -537,6 +537,25 @@ void orc_texture_value(const oscene *s, int tex, ovec3 p, double out[3]) {
 /* -------------------------------------------------------------- materials --- */
 /* material.cpp:35-40, distribution {-1,1} (material.cpp:42) */
 static ovec3 random_in_unit_sphere(orng *g) {
+    if (g->kind == ORC_RNG_STREAM) {
+        /* The per-path stream of the GPU library (rt_device.hpp, StreamRng::in_unit_sphere): the same
+         * points with the same probabilities, but an attempt first draws the top 32 bits of each
+         * coordinate and is rejected on those alone when no low bits could bring it inside. */
+        for (;;) {
+            double cx, cy, cz;
+            do {
+                cx = (double)orc_stream_next(&g->st) * 0x1p-31 - 1.0;
+                cy = (double)orc_stream_next(&g->st) * 0x1p-31 - 1.0;
+                cz = (double)orc_stream_next(&g->st) * 0x1p-31 - 1.0;
+            } while (!(cx * cx + cy * cy + cz * cz < 1.0 + 0x1p-28));
+            uint32_t l1 = orc_stream_next(&g->st), l2 = orc_stream_next(&g->st);
+            ovec3 c;
+            c.x = cx + (double)(l1 >> 11) * 0x1p-52;
+            c.y = cy + (double)(l2 >> 11) * 0x1p-52;
+            c.z = cz + (double)(((l1 & 0x7FFu) << 10) | ((l2 & 0x7FFu) >> 1)) * 0x1p-52;
+            if (c.x * c.x + c.y * c.y + c.z * c.z < 1) return c;
+        }
+    }
     for (;;) {
         ovec3 c;
         c.x = orc_uniform(g, -1, 1);

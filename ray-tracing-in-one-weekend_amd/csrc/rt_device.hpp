@@ -219,6 +219,31 @@ struct StreamRng {
     // a stream owes nobody a particular draw count: draws whose values cannot reach the
     // result may be skipped (see camera_ray)
     static constexpr bool kMaySkipDeadDraws = true;
+
+    // material.cpp:35-40 over this stream: a point of the cube [-1, 1)^3, each coordinate k 2^-52 - 1
+    // with a uniform 53-bit k as symmetric() yields it, redrawn until it lies inside the unit sphere.
+    // The low 21 bits of the three k cannot change the verdict on a point whose coarse version
+    // (the top 32 bits, X = h 2^-31 - 1) is at |X|^2 >= 1 + 2^-28: the full point is farther from the
+    // coarse one than 6 2^-31 in |.|^2 by less.  Such attempts are rejected on three generator steps
+    // instead of six; only an attempt that may pass draws its low bits (two more steps) and takes the
+    // reference's test on the full point.  Which points come out, and how often, is unchanged.
+    __device__ __forceinline__ static double coarse(uint32_t h) {
+        const double x1 = __hiloint2double((int)(0x3FF00000u | (h >> 12)), (int)(h << 20));   // 1 + h 2^-32
+        return __builtin_fma(x1, 2.0, -3.0);                                                  // exact
+    }
+    __device__ __forceinline__ void in_unit_sphere(double &x, double &y, double &z) {
+        for (;;) {
+            double cx, cy, cz;
+            do {
+                cx = coarse(next()); cy = coarse(next()); cz = coarse(next());
+            } while (!(cx * cx + cy * cy + cz * cz < 1.0 + 0x1p-28));
+            const uint32_t l1 = next(), l2 = next();
+            x = __builtin_fma((double)(l1 >> 11), 0x1p-52, cx);   // exact: 53 bits in all
+            y = __builtin_fma((double)(l2 >> 11), 0x1p-52, cy);
+            z = __builtin_fma((double)(((l1 & 0x7FFu) << 10) | ((l2 & 0x7FFu) >> 1)), 0x1p-52, cz);
+            if (x * x + y * y + z * z < 1) return;
+        }
+    }
 };
 
 // uniforms handed in by the caller, consumed in order
@@ -760,6 +785,12 @@ template <class R> __device__ __forceinline__ v3 random_in_unit_sphere(R &g) {
         c.y = g.symmetric();
         c.z = g.symmetric();
     } while (!(c.x * c.x + c.y * c.y + c.z * c.z < 1) && !g.exhausted());
+    return c;
+}
+
+__device__ __forceinline__ v3 random_in_unit_sphere(StreamRng &g) {
+    v3 c;
+    g.in_unit_sphere(c.x, c.y, c.z);
     return c;
 }
 
