@@ -566,6 +566,18 @@ static ovec3 random_in_unit_sphere(orng *g) {
     }
 }
 
+/* n points of random_in_unit_sphere over one per-path stream (test access to the stream's sampler) */
+void orc_stream_unit_sphere(uint64_t seed, uint32_t pixel, uint32_t sample, size_t n, double *out) {
+    orng g;
+    memset(&g, 0, sizeof g);
+    g.kind = ORC_RNG_STREAM;
+    orc_stream_init(&g.st, seed, pixel, sample);
+    for (size_t i = 0; i < n; ++i) {
+        ovec3 c = random_in_unit_sphere(&g);
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+}
+
 /* material.cpp:10-12 */
 static ovec3 reflect(ovec3 v, ovec3 n) { return vsub(v, vmul(n, 2 * vdot(v, n))); }
 

@@ -70,6 +70,7 @@ void     orc_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_
 void     orc_stream_init(ostream *st, uint64_t seed, uint32_t pixel, uint32_t sample);
 uint32_t orc_stream_next(ostream *st);
 double   orc_stream_canonical(ostream *st);
+void     orc_stream_unit_sphere(uint64_t seed, uint32_t pixel, uint32_t sample, size_t n, double *out /*[n][3]*/);
 
 /* a draw source: shared mt19937, per-path stream, or a tape of given uniforms */
 enum { ORC_RNG_MT = 0, ORC_RNG_STREAM = 1, ORC_RNG_TAPE = 2 };

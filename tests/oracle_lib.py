@@ -59,6 +59,7 @@ def lib():
         L.orc_stream_next.argtypes = [vp]
         L.orc_stream_next.restype = ctypes.c_uint32
         L.orc_stream_canonical.argtypes = [vp]
+        L.orc_stream_unit_sphere.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, sz, vp]
         L.orc_stream_canonical.restype = dbl
         _lib = L
     return _lib
@@ -79,6 +80,13 @@ def camera_batch(cam15, st, tape):
     used = np.zeros(len(st), np.int32)
     lib().orc_camera_batch(_ptr(cam), _ptr(st), _ptr(tape), tape.shape[1], len(st), _ptr(out), _ptr(used))
     return out, used
+
+
+def stream_unit_sphere(seed, pixel, sample, n):
+    """n points of random_in_unit_sphere drawn from the per-path stream (seed, pixel, sample)."""
+    out = np.zeros((n, 3), np.float64)
+    lib().orc_stream_unit_sphere(seed, pixel, sample, n, _ptr(out))
+    return out
 
 
 def perlin_tables():

@@ -134,3 +134,28 @@ def test_stream_mode_matches_mt_mode_statistically(orc):
     sums, _ = s.render(g["camera"], 120, 60, 0, 16, 5, orc.ORC_RNG_STREAM)
     ref = g["book2_spp256_seed1"].astype(np.float64)
     assert abs((sums / 16).mean() - ref.mean()) < 0.01
+
+
+def test_stream_unit_sphere_sampler_is_uniform_in_the_ball(orc):
+    # The per-path streams reject an attempt on the top 32 bits of its coordinates when the low bits
+    # could not bring it inside, and draw the low 21 bits only for attempts that may pass
+    # (material.cpp:35-40 is the loop it stands for).  The points must still be uniform over the
+    # 2^-52 grid inside the unit ball: inside, on the grid, radius^3 and every coordinate distributed
+    # as for the ball, low bits uniform and independent of the coarse part.
+    from scipy import stats
+    n = 400000
+    p = orc.stream_unit_sphere(7, 123, 45, n)
+    r2 = (p * p).sum(axis=1)
+    assert (r2 < 1).all() and r2.max() > 0.999
+    k = (p + 1.0) * 2.0 ** 52
+    assert np.array_equal(k, np.floor(k)) and k.min() >= 0 and k.max() < 2.0 ** 53
+    assert stats.kstest(r2 ** 1.5, "uniform").pvalue > 1e-3
+    for a in range(3):
+        x = p[:, a]
+        assert stats.kstest(x, lambda t: (2 + 3 * t - t ** 3) / 4).pvalue > 1e-3
+        low = k[:, a].astype(np.int64) & (2 ** 21 - 1)
+        assert stats.kstest(low / 2.0 ** 21, "uniform").pvalue > 1e-3
+        assert abs(np.corrcoef(low, x)[0, 1]) < 0.01
+        counts = np.bincount(low & 15, minlength=16)
+        assert stats.chisquare(counts).pvalue > 1e-3
+    assert abs(np.corrcoef(p[:, 0], p[:, 1])[0, 1]) < 0.01 and abs(np.corrcoef(p[:, 1], p[:, 2])[0, 1]) < 0.01
