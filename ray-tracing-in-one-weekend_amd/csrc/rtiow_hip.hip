@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // lane's stack; deeper nodes and all spheres are read from device memory, deeper stack
 // entries spill to it.
 constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
+constexpr size_t kCameraLds = 192;            // the block's copy of the camera
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 #ifdef RT_LANE_STATS
 constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics slots per wave of up to 1024 blocks
@@ -154,7 +155,7 @@ constexpr uint32_t kOrderMinSamples = 32;               // frames at least this 
 // DEFER: the walk postpones the box tests of static-sphere leaves (world_closest_voted); chosen
 // per scene.
 template <class AccT, bool LDS_TREE, int WAVES, bool COSTING, bool DEFER>
-__global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, uint32_t nx, uint32_t ny, uint32_t s_begin,
+__global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_arg, uint32_t nx, uint32_t ny, uint32_t s_begin,
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
                                                        uint32_t n_lleaves, uint32_t stack_cap, int *spill,
@@ -162,10 +163,16 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // LDS: [tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][leaves]
-    double *tile_sum = reinterpret_cast<double *>(lds_raw) + wave * 192;
-    char *ltree = lds_raw + kRenderWaves * 192 * sizeof(double) + (size_t)stack_cap * kRenderBlock * sizeof(int);
-    const LaneStack st = {reinterpret_cast<int *>(lds_raw + kRenderWaves * 192 * sizeof(double)) + tid, kRenderBlock, (int)stack_cap,
+    // LDS: [camera][tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][leaves]
+    // The camera's 24 doubles are needed once per path; as kernel arguments they would sit in 48
+    // scalar registers for the whole kernel and push other scalars out into vector-register lanes,
+    // to be fetched back with vector instructions in the middle of the hot loops.
+    static_assert(sizeof(DCamera) == kCameraLds, "camera copy in LDS");
+    if (tid < kCameraLds / sizeof(double)) reinterpret_cast<double *>(lds_raw)[tid] = reinterpret_cast<const double *>(&cam_arg)[tid];
+    double *tile_sum = reinterpret_cast<double *>(lds_raw + kCameraLds) + wave * 192;
+    char *const stacks = lds_raw + kCameraLds + kRenderWaves * 192 * sizeof(double);
+    char *ltree = stacks + (size_t)stack_cap * kRenderBlock * sizeof(int);
+    const LaneStack st = {reinterpret_cast<int *>(stacks) + tid, kRenderBlock, (int)stack_cap,
                           spill ? spill + (size_t)blockIdx.x * kRenderBlock + tid : nullptr, (int)(gridDim.x * kRenderBlock)};
     TreeView tree = {sc.nodes, sc.leaves, sc.prims, nullptr, nullptr, (int32_t)n_lnodes};
     {
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam, 
                         const double ii = (double)x + g.canonical();   // dist{0, 1}: u * 1 + 0 = u
                         const double jj = (double)(ny - 1 - y) + g.canonical();
                         const double u = ii / (double)nx, v = jj / (double)ny;
-                        r = camera_ray(cam, u, v, g);
+                        r = camera_ray(*reinterpret_cast<const DCamera *>(lds_raw), u, v, g);
                         thr = mk(1, 1, 1);
                         depth = 0;
                         alive = true;
@@ -784,7 +791,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     {
         const size_t sums = 192 * sizeof(double);   // per wave
         auto whole_tree = [&](int waves) {
-            return 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
+            return kCameraLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
                    fl.leaf_boxes.size() * LLEAF_STRIDE;
         };
         const char *force_waves = getenv("RTIOW_RENDER_WAVES");   // "3" keeps the 768-thread shape (tests)
@@ -805,7 +812,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             uint32_t cap = std::min<uint32_t>(stack_depth, kSpillStackCap);
             if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(1, atoi(force_cap)));
             s->render_waves = kWavesMax;
-            const size_t base = 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
+            const size_t base = kCameraLds + 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
             size_t k = std::min(fl.nodes.size(), (kLdsBudget - base - 8) / LNODE_STRIDE);
             if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
             fl.stage_top_levels(k, items);
