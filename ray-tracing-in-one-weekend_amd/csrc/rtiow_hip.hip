@@ -241,7 +241,12 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                     const uint32_t x = tile_x + (slot & (tile_side - 1u)), y = tile_y + (slot >> tile_shift);
                     if (x < nx && y < ny) {
                         const uint32_t smp = s_begin + (k >> (2u * tile_shift));
-                        g.init(seed, y * nx + x, smp);
+                        // (the seed passes through an opaque move: the ten pairs of round keys derived
+                        // from it are then formed here by scalar additions, instead of being hoisted
+                        // out of the loops into twenty scalar registers that do not exist)
+                        uint64_t seed_here = seed;
+                        asm volatile("" : "+s"(seed_here));
+                        g.init(seed_here, y * nx + x, smp);
                         // the reference's row index runs bottom-up (main.cpp:126)
                         const double ii = (double)x + g.canonical();   // dist{0, 1}: u * 1 + 0 = u
                         const double jj = (double)(ny - 1 - y) + g.canonical();
