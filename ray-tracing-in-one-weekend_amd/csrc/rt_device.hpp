@@ -64,8 +64,9 @@ enum : uint32_t { NF_SAFE0 = 1u, NF_SAFE1 = 2u };
 // it has a second sphere; bits 29, 30: first / second sphere is a moving sphere
 constexpr int32_t LEAF_BIT = (int32_t)0x80000000u;
 constexpr int32_t LEAF_SAFE = 1 << 27, LEAF_TWO = 1 << 28, LEAF_MOVING0 = 1 << 29, LEAF_MOVING1 = 1 << 30;
-constexpr int32_t LEAF_INDEX_MASK = 0x07FFFFFF;
-constexpr int32_t REF_NONE = (int32_t)0x87FFFFFFu;   // a leaf number no scene can reach
+constexpr int32_t LEAF_SECOND = 1 << 26;             // without LEAF_TWO: the reference is to the leaf's second sphere alone
+constexpr int32_t LEAF_INDEX_MASK = 0x03FFFFFF;
+constexpr int32_t REF_NONE = (int32_t)0x83FFFFFFu;   // a leaf number no scene can reach
 
 enum : uint32_t { PK_STATIC = 0, PK_MOVING = 1, PK_MOVING_UNIT = 2 };
 
@@ -454,6 +455,8 @@ __device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, f
 constexpr uint32_t LNODE_STRIDE = 68;    // bx[2][6] floats | child[2] | flags
 constexpr uint32_t LPRIM_BYTES = 88;     // c0[3] r*r dc[3] t0 t1 | mat kind orig pad
 constexpr uint32_t LLEAF_STRIDE = 232;   // box[6] doubles | sphere | sphere | pad
+// scenes without moving spheres: box[6] | c0[3] r*r | c0[3] r*r | pad (an odd number of 8-byte words)
+constexpr uint32_t SPRIM_BYTES = 32, SLEAF_STRIDE = 120;
 
 // Where a walk finds the tree.  The block's LDS holds the first n_lnodes nodes (all of them
 // when the tree fits, else its top levels: nodes are numbered breadth-first there) and,
@@ -550,21 +553,38 @@ __device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim
 //
 // `box_now` = false postpones the box test of a leaf of static spheres: its spheres are tried at once
 // and the caller tests the box of the winning leaf only (see world_closest_voted).
-// ALL_STATIC: the scene has no moving sphere, so every leaf is SAFE and the flags are not looked at.
+// ALL_STATIC: the scene has no moving sphere.  Every leaf is SAFE, every reference is to one sphere
+// (leaves of two were split on upload, see flattener::split_pairs), and the LDS records are the
+// compact ones.
 template <bool SPILL, bool ALL_STATIC = false>
 __device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx &r, double tmin, double tmax, const LaneStack &st, Trav &tv, bool box_now) {
     const int32_t ref = tv.cur;
     const int32_t leaf = ref & LEAF_INDEX_MASK;
-    const char *rec = lleaves + (uint32_t)leaf * LLEAF_STRIDE;
-    const bool safe = ALL_STATIC || (ref & LEAF_SAFE);
-    bool reached = true;
-    if (box_now || !safe) {
-        double entry;
-        reached = box_test_ordered(rec, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
-    }
-    if (reached) {
-        leaf_candidate_lds(rec + 48, 2 * leaf, !ALL_STATIC && (ref & LEAF_MOVING0), r, tmin, tmax, tv);
-        if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, !ALL_STATIC && (ref & LEAF_MOVING1), r, tmin, tmax, tv);
+    if (ALL_STATIC) {
+        const char *rec = lleaves + (uint32_t)leaf * SLEAF_STRIDE;
+        bool reached = true;
+        if (box_now) {
+            double entry;
+            reached = box_test_ordered(rec, r, tmin, tmax, entry) && (tv.bp < 0 || entry <= tv.bt);
+        }
+        if (reached) {
+            const uint32_t k = (ref & LEAF_SECOND) ? 1u : 0u;
+            const double *p = reinterpret_cast<const double *>(rec + 48 + k * SPRIM_BYTES);
+            double t;
+            if (sphere_root(mk(p[0], p[1], p[2]), p[3], r, tmin, tmax, t)) take_if_closer(t, 2 * leaf + (int32_t)k, tv);
+        }
+    } else {
+        const char *rec = lleaves + (uint32_t)leaf * LLEAF_STRIDE;
+        const bool safe = ref & LEAF_SAFE;
+        bool reached = true;
+        if (box_now || !safe) {
+            double entry;
+            reached = box_test_ordered(rec, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
+        }
+        if (reached) {
+            leaf_candidate_lds(rec + 48, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
+            if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+        }
     }
     tv.cur = trav_pop<SPILL>(tv, st);
 }
@@ -582,8 +602,14 @@ __device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prim
         reached = box_test(bx, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
     }
     if (reached) {
-        leaf_candidate(prims, 2 * leaf, !ALL_STATIC && (ref & LEAF_MOVING0), r, tmin, tmax, tv);
-        if (ref & LEAF_TWO) leaf_candidate(prims, 2 * leaf + 1, !ALL_STATIC && (ref & LEAF_MOVING1), r, tmin, tmax, tv);
+        // the first sphere of the reference: the leaf's first, or its second on its own (a split leaf)
+        const int32_t first = 2 * leaf + ((ref & LEAF_SECOND) ? 1 : 0);
+        if (ALL_STATIC) {
+            leaf_candidate(prims, first, false, r, tmin, tmax, tv);
+        } else {
+            leaf_candidate(prims, first, ref & ((ref & LEAF_SECOND) ? LEAF_MOVING1 : LEAF_MOVING0), r, tmin, tmax, tv);
+            if (ref & LEAF_TWO) leaf_candidate(prims, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+        }
     }
     tv.cur = trav_pop<SPILL>(tv, st);
 }
@@ -592,7 +618,7 @@ __device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prim
 template <bool LDS_TREE>
 __device__ __forceinline__ bool leaf_box_reached(const TreeView &tree, int32_t leaf, const RayCtx &r, double tmin, double tmax) {
     double entry;
-    if (LDS_TREE) return box_test_ordered(tree.lleaves + (uint32_t)leaf * LLEAF_STRIDE, r, tmin, tmax, entry);
+    if (LDS_TREE) return box_test_ordered(tree.lleaves + (uint32_t)leaf * SLEAF_STRIDE, r, tmin, tmax, entry);   // (static scenes only)
     double bx[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) bx[k] = tree.leaves[leaf].box[k];

@@ -184,7 +184,18 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
             if (LDS_TREE && (w == 12u || w == 13u) && (int32_t)v >= 0) v *= LNODE_STRIDE;
             reinterpret_cast<uint32_t *>(lnodes + (size_t)n * LNODE_STRIDE)[w] = v;
         }
-        for (uint32_t i = tid; i < n_lleaves * 28u; i += kRenderBlock) {   // 6 doubles of the box, 11 of each sphere record
+        for (uint32_t i = tid; DEFER && i < n_lleaves * 14u; i += kRenderBlock) {   // static scenes: 6 doubles of the box, centre and r*r of each sphere
+            const uint32_t n = i / 14u, w = i % 14u;
+            double v;
+            if (w < 6u) v = sc.leaves[n].box[w];
+            else {
+                const DPrim *p = sc.prims + 2u * n + (w - 6u) / 4u;
+                const uint32_t f = (w - 6u) % 4u;
+                v = f < 3u ? p->c0[f] : p->r * p->r;   // the sphere test wants radius * radius (sphere.cpp:16)
+            }
+            reinterpret_cast<double *>(lleaves + (size_t)n * SLEAF_STRIDE)[w] = v;
+        }
+        for (uint32_t i = tid; !DEFER && i < n_lleaves * 28u; i += kRenderBlock) {   // 6 doubles of the box, 11 of each sphere record
             const uint32_t n = i / 28u, w = i % 28u;
             double v;
             if (w < 6u) v = sc.leaves[n].box[w];
@@ -461,7 +472,7 @@ struct flattener {
     // before it tries them (min x, max x, min y, ...; unbounded when it tries them unconditionally)
     int32_t leaf_of(int32_t prim_a, int32_t prim_b, const double *box, bool &safe) {
         bool sa = true, sb = true;
-        if (leaf_boxes.size() >= (size_t)LEAF_INDEX_MASK) { error = "more than 2^27 leaves"; return REF_NONE; }
+        if (leaf_boxes.size() >= (size_t)LEAF_INDEX_MASK) { error = "more than 2^26 leaves"; return REF_NONE; }
         int32_t ref = LEAF_BIT | (int32_t)leaf_boxes.size();
         DLeaf lf;
         memcpy(lf.box, box, sizeof lf.box);
@@ -657,6 +668,48 @@ struct flattener {
         return me;
     }
 
+    // Scenes of static spheres only: every leaf of two spheres becomes one more node over two
+    // one-sphere references, each with the sphere's own box.  The reference's leaves pair
+    // neighbours along a random axis (bvh_node.cpp:9-41), so a leaf's box is mostly empty: of the rays
+    // that reach one, a few per cent meet the line of either sphere.  With its own box in the way
+    // a sphere is tried by about as many rays as hit it.  A ray the sphere test accepts passes
+    // within the radius of the centre up to the rounding of the test, which the padding below and
+    // the conservative node test's margins exceed by orders of magnitude, so no candidate of the
+    // reference's is lost; the reference's test of the leaf's box is applied as before (to the winner,
+    // or in the exact walk, once per sphere reached).
+    void split_pairs(std::vector<DItem> &items) {
+        const size_t n = nodes.size();
+        bool any = false;
+        auto sphere_box = [&](int32_t prim, double *b) {
+            const DPrim &p = prims[(size_t)prim];
+            const double r = std::fabs(p.r) * (1.0 + 0x1p-20);
+            for (int a = 0; a < 3; ++a) { b[2 * a] = p.c0[a] - r; b[2 * a + 1] = p.c0[a] + r; }
+        };
+        auto split = [&](int32_t ref) -> int32_t {
+            const int32_t leaf = ref & LEAF_INDEX_MASK;
+            DNode nd;
+            memset(&nd, 0, sizeof nd);
+            double b[6];
+            for (int k = 0; k < 2; ++k) {
+                sphere_box(2 * leaf + k, b);
+                set_child_box(nd, k, b);
+                nd.child[k] = LEAF_BIT | LEAF_SAFE | leaf | (k ? LEAF_SECOND : 0);
+            }
+            nd.flags = NF_SAFE0 | NF_SAFE1;
+            nodes.push_back(nd);
+            any = true;
+            return (int32_t)nodes.size() - 1;
+        };
+        for (size_t i = 0; i < n; ++i)
+            for (int c = 0; c < 2; ++c) {
+                const int32_t ref = nodes[i].child[c];
+                if (ref < 0 && (ref & LEAF_TWO)) { const int32_t nn = split(ref); nodes[i].child[c] = nn; }
+            }
+        for (DItem &it : items)
+            if (it.has_box && it.ref < 0 && (it.ref & LEAF_TWO)) it.ref = split(it.ref);
+        if (any) ++max_depth;
+    }
+
     // Renumbers the nodes so that the k nearest to the roots, breadth-first, come first (the
     // part of a large tree the render kernel keeps in LDS); the others keep their order.
     void stage_top_levels(size_t k, std::vector<DItem> &items) {
@@ -786,6 +839,13 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     std::unique_ptr<rt_scene> owner(new rt_scene);   // freed on every early return
     rt_scene *s = owner.get();
     s->device = device;
+    // Scenes without a moving sphere run the kernel variant that postpones the leaves' box tests to
+    // the winning leaf and skips behind the best hit without consulting flags (k_render's DEFER), on
+    // a tree whose leaves are single spheres.  RTIOW_STATIC_VARIANT=0 keeps the general variant and
+    // the reference's leaves (tests, A/B).
+    const char *static_env = getenv("RTIOW_STATIC_VARIANT");
+    const bool static_scene = fl.n_moving_leaves == 0 && !fl.nodes.empty() && !(static_env && atoi(static_env) == 0);
+    if (static_scene) fl.split_pairs(items);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
@@ -797,7 +857,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         const size_t sums = 192 * sizeof(double);   // per wave
         auto whole_tree = [&](int waves) {
             return kCameraLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
-                   fl.leaf_boxes.size() * LLEAF_STRIDE;
+                   fl.leaf_boxes.size() * (static_scene ? SLEAF_STRIDE : LLEAF_STRIDE);
         };
         const char *force_waves = getenv("RTIOW_RENDER_WAVES");   // "3" keeps the 768-thread shape (tests)
         const int waves_fit = whole_tree(kWavesMax) <= kLdsBudget && !(force_waves && atoi(force_waves) == kWavesMin) ? kWavesMax : kWavesMin;
@@ -892,13 +952,10 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = stack_depth;
-    // Scenes without a moving sphere run the kernel variant that postpones the leaves' box tests to
-    // the winning leaf and skips behind the best hit without consulting flags (k_render's DEFER).
-    // RTIOW_DEFER_LEAF_BOXES=0 keeps the general variant; RTIOW_RECHECK_ALL_LEAVES makes every hit
-    // take the second, exact walk (both for tests).
+    // RTIOW_RECHECK_ALL_LEAVES makes every hit of the static-scene variant take its second, exact
+    // walk (tests).
     {
-        const char *defer_env = getenv("RTIOW_DEFER_LEAF_BOXES");
-        s->render_defer = !fl.nodes.empty() && fl.n_moving_leaves == 0 && !(defer_env && atoi(defer_env) == 0);
+        s->render_defer = static_scene;
         s->d.recheck_all = getenv("RTIOW_RECHECK_ALL_LEAVES") ? 1u : 0u;
     }
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);

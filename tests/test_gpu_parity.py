@@ -472,23 +472,24 @@ def test_large_tree_kernel_shape_on_small_scenes(rt, orc, scene, lds_nodes, stac
 
 @pytest.mark.parametrize("scene", ["book1", "book2", "stress4096", "mixed", "ties"])
 def test_postponed_leaf_box_tests_change_nothing(rt, orc, scene, monkeypatch):
-    # In scenes without moving spheres the render kernel tries a leaf's spheres first and runs the
-    # reference's test of the leaf's box (bvh_node.cpp:53 -> aabb.cpp:8-57) for the winning leaf only,
-    # walking again with every box tested up front if that one fails.  Off, on, on with every hit sent
+    # Scenes without moving spheres get their own kernel variant and tree: leaves of two spheres are
+    # split into single spheres with their own boxes, a sphere is tried before its leaf's box, and the
+    # reference's test of that box (bvh_node.cpp:53 -> aabb.cpp:8-57) runs for the winning leaf only,
+    # with a second walk that tests every box up front if it fails.  Off, on, on with every hit sent
     # through the second walk, and the same on the large-tree shape: one frame, to the bit, and the
     # oracle's.  (Scenes with moving spheres always run the general kernel: the switch does nothing.)
     cam15 = np.array(golden("frames")["camera"])
     cam15[10] = 2.0
     frames = []
     for defer, recheck, lds_nodes in [("0", False, None), ("1", False, None), ("1", True, None), ("1", False, "9"), ("1", True, "9")]:
-        monkeypatch.setenv("RTIOW_DEFER_LEAF_BOXES", defer)
+        monkeypatch.setenv("RTIOW_STATIC_VARIANT", defer)
         if recheck:
             monkeypatch.setenv("RTIOW_RECHECK_ALL_LEAVES", "1")
         if lds_nodes:
             monkeypatch.setenv("RTIOW_RENDER_LDS_NODES", lds_nodes)
             monkeypatch.setenv("RTIOW_RENDER_STACK_CAP", "2")
         w = rt.World(recipe(scene))
-        for name in ("RTIOW_DEFER_LEAF_BOXES", "RTIOW_RECHECK_ALL_LEAVES", "RTIOW_RENDER_LDS_NODES", "RTIOW_RENDER_STACK_CAP"):
+        for name in ("RTIOW_STATIC_VARIANT", "RTIOW_RECHECK_ALL_LEAVES", "RTIOW_RENDER_LDS_NODES", "RTIOW_RENDER_STACK_CAP"):
             monkeypatch.delenv(name, raising=False)
         try:
             frames.append(w.render(rt.camera(cam15), 72, 36, 0, 5, 33))
