@@ -680,11 +680,6 @@ struct flattener {
     void split_pairs(std::vector<DItem> &items) {
         const size_t n = nodes.size();
         bool any = false;
-        auto sphere_box = [&](int32_t prim, double *b) {
-            const DPrim &p = prims[(size_t)prim];
-            const double r = std::fabs(p.r) * (1.0 + 0x1p-20);
-            for (int a = 0; a < 3; ++a) { b[2 * a] = p.c0[a] - r; b[2 * a + 1] = p.c0[a] + r; }
-        };
         auto split = [&](int32_t ref) -> int32_t {
             const int32_t leaf = ref & LEAF_INDEX_MASK;
             DNode nd;
@@ -740,11 +735,37 @@ struct flattener {
             if (it.ref >= 0) it.ref = renum[it.ref];
     }
 
+    // the box a one-sphere reference gets in a scene of static spheres (see split_pairs)
+    void sphere_box(int32_t prim, double *b) const {
+        const DPrim &p = prims[(size_t)prim];
+        const double r = std::fabs(p.r) * (1.0 + 0x1p-20);
+        for (int a = 0; a < 3; ++a) { b[2 * a] = p.c0[a] - r; b[2 * a + 1] = p.c0[a] + r; }
+    }
+
+    bool static_scene = false;   // no moving sphere: the tree is built over single spheres
+
     // the whole bvh item rooted at description node `id`, re-clustered
     int32_t build_clustered(int32_t id, bool &safe) {
         leaves.clear();
         collect(id, 0);
         if (error) return REF_NONE;
+        if (static_scene) {
+            // cluster the spheres themselves rather than the reference's pairs of them: the pairs are
+            // neighbours along a random axis, and a tree over their mostly empty boxes stays loose
+            std::vector<leaf_rec> singles;
+            singles.reserve(2 * leaves.size());
+            for (const leaf_rec &lr : leaves) {
+                const int32_t leaf = lr.ref & LEAF_INDEX_MASK;
+                for (int k = 0; k < ((lr.ref & LEAF_TWO) ? 2 : 1); ++k) {
+                    leaf_rec one;
+                    one.ref = LEAF_BIT | LEAF_SAFE | leaf | (k ? LEAF_SECOND : 0);
+                    sphere_box(2 * leaf + k, one.box);
+                    one.safe = true;
+                    singles.push_back(one);
+                }
+            }
+            leaves.swap(singles);
+        }
         if (leaves.size() == 1) { safe = leaves[0].safe; return leaves[0].ref; }
         double box[6];
         return cluster(0, leaves.size(), 0, box, safe);
@@ -819,6 +840,11 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     const char *tree_env = getenv("RTIOW_TREE");
     const bool reference_layout = tree_env && strcmp(tree_env, "reference") == 0;
     fl.desc = desc;
+    // RTIOW_STATIC_VARIANT=0 treats a scene without moving spheres like any other (tests, A/B)
+    const char *static_env = getenv("RTIOW_STATIC_VARIANT");
+    fl.static_scene = !(static_env && atoi(static_env) == 0);
+    for (uint32_t i = 0; i < desc->n_prims; ++i)
+        if (desc->prims[i].kind == RT_PRIM_MOVING_SPHERE) fl.static_scene = false;
     std::vector<DItem> items;
     for (uint32_t i = 0; i < desc->n_items; ++i) {
         const rt_item_desc &it = desc->items[i];
@@ -843,9 +869,8 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     // the winning leaf and skips behind the best hit without consulting flags (k_render's DEFER), on
     // a tree whose leaves are single spheres.  RTIOW_STATIC_VARIANT=0 keeps the general variant and
     // the reference's leaves (tests, A/B).
-    const char *static_env = getenv("RTIOW_STATIC_VARIANT");
-    const bool static_scene = fl.n_moving_leaves == 0 && !fl.nodes.empty() && !(static_env && atoi(static_env) == 0);
-    if (static_scene) fl.split_pairs(items);
+    const bool static_scene = fl.static_scene && !fl.nodes.empty();
+    if (static_scene) fl.split_pairs(items);   // (what re-clustering left whole: the reference layout's leaves)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
