@@ -738,7 +738,10 @@ struct flattener {
     // the box a one-sphere reference gets in a scene of static spheres (see split_pairs)
     void sphere_box(int32_t prim, double *b) const {
         const DPrim &p = prims[(size_t)prim];
-        const double r = std::fabs(p.r) * (1.0 + 0x1p-20);
+        // the radius, 2^-20 of it, and 2^-30 of the largest coordinate (a radius of zero, or one far
+        // below the centre's magnitude, still gets a box wider than the test's rounding)
+        const double far = std::fmax(std::fmax(std::fabs(p.c0[0]), std::fabs(p.c0[1])), std::fabs(p.c0[2]));
+        const double r = std::fabs(p.r) * (1.0 + 0x1p-20) + 0x1p-30 * (far + std::fabs(p.r));
         for (int a = 0; a < 3; ++a) { b[2 * a] = p.c0[a] - r; b[2 * a + 1] = p.c0[a] + r; }
     }
 

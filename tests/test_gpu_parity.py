@@ -502,6 +502,38 @@ def test_postponed_leaf_box_tests_change_nothing(rt, orc, scene, monkeypatch):
     np.testing.assert_allclose(frames[0][0], exp, rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("scene", ["book1", "stress4096", "ties"])
+def test_grazing_rays_reach_their_spheres(rt, orc, scene):
+    # In a scene without moving spheres every sphere sits behind a box of its own (single precision,
+    # padded, tested conservatively).  A ray the reference's sphere test accepts by the last bit of its
+    # discriminant must still get through that box: rays aimed at the limb of random spheres, from near
+    # and far, off by 0, a few ulps, ... 1e-9 of the radius either way, must give the oracle's hits.
+    spheres = np.array([[float(x) for x in l.split()[2:6]] for l in open(recipe(scene)) if l.startswith("sphere ")])
+    rng = np.random.default_rng(77)
+    n = 60000
+    pick = spheres[rng.integers(0, len(spheres), n)]
+    c, r = pick[:, :3], pick[:, 3]
+    axis = rng.normal(size=(n, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    side = np.cross(axis, rng.normal(size=(n, 3))); side /= np.linalg.norm(side, axis=1, keepdims=True)
+    eps = rng.choice([0.0, 1e-16, -1e-16, 4e-16, -4e-16, 1e-14, -1e-14, 1e-12, -1e-12, 1e-9, -1e-9, 1e-6, -1e-6], n)
+    limb = c + side * (np.abs(r) * (1.0 + eps))[:, None]
+    dist = np.abs(r)[:, None] * rng.choice([1.5, 10.0, 300.0, 5000.0], n)[:, None]
+    o = limb - axis * dist
+    d = axis * rng.choice([1.0, 0.37, 12.5], n)[:, None]
+    rays = np.hstack([o, d, np.zeros((n, 1))])
+    w = rt.World(recipe(scene))
+    try:
+        h = w.trace(rays, 0.001, np.finfo(np.float64).max)
+    finally:
+        w.close()
+    hit, prim, tpn = orc.Scene(recipe(scene)).trace(rays, 0.001, np.finfo(np.float64).max)
+    assert np.array_equal(h["hit"], hit.astype(np.int32))
+    assert np.array_equal(h["prim"], prim)
+    m = hit == 1
+    assert np.array_equal(h["t"][m], tpn[m, 0])
+    assert 0.2 < m.mean() < 1.0
+
+
 def test_cost_ordered_tiles_render_the_same_frame(rt, worlds, monkeypatch):
     # Deep frames with many tiles get a costing pass and are rendered dearest tile first.  Which wave
     # renders which tile when must not change a bit of the image or the ray count.
