@@ -22,13 +22,15 @@ namespace rtd {
 // it may let a ray into a subtree the reference would have skipped, never the reverse.  What
 // the reference computes -- the double-precision test of aabb.cpp:8-57 -- is done on the box of
 // each leaf (DLeaf) before its spheres are tried: the walk reaches a superset of the
-// reference's leaves and that test removes the excess.
+// reference's leaves and that test removes the excess.  (In scenes without moving spheres the tree
+// goes down to single spheres, each behind a box of its own, and the render kernel applies the
+// leaf's test to the winning hit only: see world_closest_voted.)
 //
 // A leaf is a reference node whose children are primitives (bvh_node.cpp:31-37: one object
 // twice, or two objects); its one or two spheres are entries 2*leaf and 2*leaf+1 of the
 // primitive table.
 struct __attribute__((aligned(16))) DNode {
-    float bx[2][6];    // per child: min x, max x, min y, max y, min z, max z (rounded outward)
+    float bx[2][6];    // per child: min x, max x, min y, max y, min z, max z (plane_down / plane_up)
     int32_t child[2];  // >= 0 node index, < 0 leaf reference (see leaf_ref)
     uint32_t flags;    // NF_SAFE0 | NF_SAFE1
     uint32_t pad;
@@ -60,8 +62,9 @@ __host__ __device__ inline float plane_up(double v) {
 // always visited, as the reference visits them.
 enum : uint32_t { NF_SAFE0 = 1u, NF_SAFE1 = 2u };
 
-// leaf reference: bit 31 set; bits 0-26 leaf number; bit 27: all its spheres are static; bit 28:
-// it has a second sphere; bits 29, 30: first / second sphere is a moving sphere
+// leaf reference: bit 31 set; bits 0-25 leaf number; bit 26: the leaf's second sphere alone (trees over
+// single spheres, see flattener::split_pairs); bit 27: all its spheres are static; bit 28: both
+// spheres of the leaf; bits 29, 30: first / second sphere is a moving sphere
 constexpr int32_t LEAF_BIT = (int32_t)0x80000000u;
 constexpr int32_t LEAF_SAFE = 1 << 27, LEAF_TWO = 1 << 28, LEAF_MOVING0 = 1 << 29, LEAF_MOVING1 = 1 << 30;
 constexpr int32_t LEAF_SECOND = 1 << 26;             // without LEAF_TWO: the reference is to the leaf's second sphere alone
