@@ -84,7 +84,9 @@ static_assert(sizeof(DPrim) == 96, "DPrim layout");
 // One entry of the world's object_list.  ref is a node index or a leaf reference;
 // has_box = 0 for a bare primitive in the list (object_list.cpp:18 tries it directly).
 struct DItem { int32_t ref; uint32_t has_box; };
-struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; };
+// inv_ri = 1 / ri and r0sq = ((1 - ri) / (1 + ri))^2, as material.cpp:81 and :27-28 form them on every
+// call, are formed once at upload
+struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; double inv_ri; double r0sq; };
 struct DTex { uint32_t kind; uint32_t even, odd; uint32_t pad; double c[3]; };
 
 struct DScene {
@@ -856,7 +858,7 @@ __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ra
     const bool inside = dn > 0;
     const v3 outward = inside ? vneg(n) : n;
     const v3 reflected = reflect(r.d, n);
-    const double ni_over_nt = inside ? ri : 1 / ri;
+    const double ni_over_nt = inside ? ri : m->inv_ri;
     const double len = vlen(r.d);
     const double cosine = inside ? ri * dn / len : -dn / len;
     const v3 uv = vdiv(r.d, len);
@@ -866,8 +868,7 @@ __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ra
     v3 refracted = reflected;
     if (disc > 0) {
         refracted = vsub(vmul(vsub(uv, vmul(outward, dt)), ni_over_nt), vmul(outward, sqrt(disc)));
-        double r0 = (1 - ri) / (1 + ri);
-        double r1 = r0 * r0;
+        const double r1 = m->r0sq;
         // schlick (material.cpp:26-30).  pow(x, 5) is taken by repeated multiplication: at most
         // 2 ulp from a correctly rounded pow, and the value is only compared with a uniform.
         const double x = 1 - cosine, x2 = x * x;

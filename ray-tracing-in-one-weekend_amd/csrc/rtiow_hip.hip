@@ -926,6 +926,8 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         DMat d;
         memset(&d, 0, sizeof d);
         d.kind = m.kind; d.tex = m.texture; d.fuzz = m.fuzziness; d.ri = m.refractive_index;
+        d.inv_ri = 1 / d.ri;
+        { const double r0 = (1 - d.ri) / (1 + d.ri); d.r0sq = r0 * r0; }
         for (int k = 0; k < 3; ++k) d.albedo[k] = m.albedo[k];
         mats[i] = d;
     }
