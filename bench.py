@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--total-spp S]
 
-One step = one pass of the hot path over one frame's worth of samples: every rank renders
-`--spp` samples of every pixel of the 1920x1080 random-spheres frame (BASELINE.json
-configs[1]) with the per-(pixel, sample) random streams, rank r taking the global sample
-indices [r*spp, (r+1)*spp), and the float accumulation buffers are summed with one RCCL
-all-reduce (weak scaling: per-GPU work is fixed as N grows).  The scene is uploaded once
-and stays resident in HBM; only kernels and the all-reduce are inside the timed region.
+One step = one pass of the hot path over one frame's worth of samples.  Default (c2, weak
+scaling): every rank renders `--spp` samples of every pixel of the 1920x1080 random-spheres
+frame (BASELINE.json configs[1]), rank r taking the global sample indices [r*spp, (r+1)*spp),
+and the float accumulation buffers are summed with one RCCL all-reduce.  With `--total-spp S`
+(or `--config c4`: 3840x2160, S = 4096, BASELINE.json configs[3]) the frame's S samples are
+SPLIT across the ranks, rank g taking [g*S/G, (g+1)*S/G) -- strong scaling.  The per-(pixel,
+sample) random streams make the union of the ranks' paths the same set for any G.  The scene
+is uploaded once and stays resident in HBM; only kernels and the all-reduce are timed.
 
-Rank 0 prints ONE JSON line.  `value` is whole-job Mpaths/s (1 path = 1 camera sample
-followed through all its bounces).  `roofline` prices the render kernel against HBM peak
-with the algorithmic bytes of reference-semantics traversal (32 B per box test, 16 B per
-static-sphere test, 40 B per moving-sphere test, 12 B of framebuffer per pixel), the
-per-path counts measured by the CPU oracle on the same scene and camera.  `cpu_baseline`
-times the compiled reference classes (oracle/_ref/ref_capture) -- or the C oracle when
-that binary is absent -- on one host core over a bounded sample of the same frame.
+Rank 0 prints ONE JSON line.  `value` is whole-job Mpaths/s (1 path = 1 camera sample followed
+through all its bounces).
+
+`roofline` is the bound that binds this kernel: vector-ALU issue.  The tree lives in LDS and
+HBM is idle, so the kernel is priced in VALU lane-slots: a SIMD issues 16 lanes per cycle, the
+chip 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-slots/s, which is the 78.6 TFLOP/s
+FP64 peak at 2 flop per slot.  `achieved` = lane-slots the kernel occupied per launch (the
+SQ_THREAD_CYCLES_VALU counter of the PMC pass over this very configuration, kept in
+profiles/valu.json) x 2 / the kernel's launch duration measured live with HIP events, i.e.
+an FMA-equivalent rate: what the same slots would deliver if every instruction were an f64
+FMA.  `frac` = achieved / peak <= 1.  `lanes_active`, `valu_busy` and `occupancy` come from
+the same pass.  `algorithmic_hbm` keeps the figure that prices the REFERENCE's traversal
+(32 B per box test, ...) against HBM peak: reference-work-equivalents, which this kernel
+neither fetches nor executes -- it can exceed 1 and says nothing about the hardware.
+
+`cpu_baseline` times the compiled reference classes (oracle/_ref/ref_capture) -- or the C
+oracle when that binary is absent -- on one host core over a bounded sample of the frame.
+`extra_configs` (N = 1 only) adds short runs of the other BASELINE configurations.
 """
 import argparse
 import importlib
@@ -33,8 +46,8 @@ sys.path.insert(0, ROOT)
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
-FP64_PEAK_TFLOPS = 78.6      # MI355X vector FP64
-
+FP64_PEAK_TFLOPS = 78.6      # MI355X vector FP64 = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+LANE_SLOTS_PER_S = 256 * 4 * 16 * 2.4e9
 
 WORKLOADS = {
     "book1": "book-1 random spheres, ~485 static spheres, lambertian/metal/dielectric (BASELINE configs[1])",
@@ -43,10 +56,36 @@ WORKLOADS = {
     "stress": "synthetic sphere field, one bvh over everything (BASELINE configs[4])",
 }
 
+# BASELINE.json configs[1..4]
+CONFIGS = {
+    "c2": dict(scene="book1", nx=1920, ny=1080, spp=1024, total_spp=None, camera="book"),
+    "c3": dict(scene="book2", nx=1920, ny=1080, spp=1024, total_spp=None, camera="book"),
+    "c4": dict(scene="book1", nx=3840, ny=2160, spp=None, total_spp=4096, camera="book"),
+    "c5": dict(scene="stress:1000000", nx=1920, ny=1080, spp=64, total_spp=None, camera="0,25,60,0,0,0,40"),
+}
+
 
 def book_camera(aspect):
     # main.cpp:114-120
     return [13.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 20.0, aspect, 0.0, 10.0, 0.0, 1.0]
+
+
+def camera15(spec, aspect):
+    cam15 = book_camera(aspect)
+    if spec != "book":            # 'fx,fy,fz,ax,ay,az,vfov'
+        v = [float(x) for x in spec.split(",")]
+        cam15[0:6] = v[0:6]
+        cam15[9] = v[6]
+    return cam15
+
+
+def scene_file(rt, scene):
+    if scene.startswith("stress:"):          # e.g. stress:1000000 -- generated on the fly (configs[4])
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), f"rtiow_{scene.replace(':', '_')}_{os.getpid()}.recipe")
+        rt.generate("stress", 1, path, n=int(scene.split(":")[1]))
+        return path
+    return scene if os.path.exists(scene) else os.path.join(SCENES, scene + ".recipe")
 
 
 def algorithmic_counts(scene_path, cam15):
@@ -104,27 +143,113 @@ def cpu_baseline(scene_path, cam15, nx, ny):
 
 
 def image_check(rt, world, scene):
-    """RMSE of a 120x60, 256-spp GPU frame against a frame the reference rendered at the same
-    size and sample count (tests/golden/frames.npz), beside the RMSE between two reference
+    """RMSE of a 400x200, 1024-spp GPU frame against a frame the reference rendered at the same
+    size and sample count (tests/golden/frames_1024.npz), beside the RMSE between two reference
     seeds: two independent estimates of the same image differ by about that much."""
-    path = os.path.join(ROOT, "tests", "golden", "frames.npz")
+    path = os.path.join(ROOT, "tests", "golden", "frames_1024.npz")
     if not os.path.exists(path):
         return None
     g = np.load(path)
-    if scene + "_spp256_seed1" not in g.files:
+    if scene + "_spp1024_seed1" not in g.files:
         return None
-    a, b = g[scene + "_spp256_seed1"].astype(np.float64), g[scene + "_spp256_seed2"].astype(np.float64)
-    sums, _ = world.render(rt.camera(g["camera"]), 120, 60, 0, 256, 77)
-    img = sums / 256
+    a, b = g[scene + "_spp1024_seed1"].astype(np.float64), g[scene + "_spp1024_seed2"].astype(np.float64)
+    sums, _ = world.render(rt.camera(g["camera"]), 400, 200, 0, 1024, 77)
+    img = sums / 1024
     return {"rmse_vs_reference": float(np.sqrt(np.mean((img - a) ** 2))), "rmse_between_reference_seeds": float(np.sqrt(np.mean((a - b) ** 2))),
-            "frame": "120x60, 256 spp, linear radiance"}
+            "mean_vs_reference": [float(x) for x in (img.mean(axis=(0, 1)) - 0.5 * (a + b).mean(axis=(0, 1)))],
+            "frame": "400x200, 1024 spp, linear radiance"}
 
 
-def sample_range(rank, spp):
+def sample_range(rank, spp, world=1, total_spp=None):
     """Global sample indices [begin, end) that rank `rank` renders of every pixel: disjoint
     across ranks, and -- the streams being keyed by (pixel, global sample) -- together the same
-    set of paths a single GPU would trace for world*spp samples."""
+    set of paths a single GPU would trace.  Weak scaling: `spp` per rank.  Strong scaling
+    (`total_spp` given): the frame's total_spp samples split [g*S/G, (g+1)*S/G)."""
+    if total_spp is not None:
+        return rank * total_spp // world, (rank + 1) * total_spp // world
     return rank * spp, (rank + 1) * spp
+
+
+def valu_roofline(config_key, kernel_s):
+    """The binding bound from the PMC pass kept in profiles/valu.json (collected by
+    tools/profile_round.sh on exactly `config_key`; None for any other configuration)."""
+    path = os.path.join(ROOT, "profiles", "valu.json")
+    if not os.path.exists(path):
+        return None
+    v = json.load(open(path))
+    if v.get("config_key") != config_key:
+        return None
+    slots = v["SQ_THREAD_CYCLES_VALU"]
+    achieved = 2.0 * slots / kernel_s / 1e12
+    out = {"bound": "valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+           "meaning": "VALU lane-slots occupied per launch (SQ_THREAD_CYCLES_VALU of the PMC pass over this configuration) x 2 flop / live kernel time: "
+                      "FMA-equivalent rate against the f64 vector peak at the nominal 2.4 GHz",
+           "lane_slots_per_launch": slots, "source": "profiles/valu.json <- " + v.get("source", "?")}
+    for k in ("lanes_active", "valu_busy", "occupancy", "valu_insts_per_launch", "f64_flops_per_launch", "pmc_kernel_ms"):
+        if k in v:
+            out[k] = v[k]
+    if "f64_flops_per_launch" in v:
+        out["executed_f64_tflops"] = v["f64_flops_per_launch"] / kernel_s / 1e12
+    return out
+
+
+def run_steps(torch, world_obj, cam, params, accum, stream, steps, warmup):
+    """`warmup` untimed and `steps` timed single-GPU frames; returns (wall seconds, kernel ms list, last stats)."""
+    rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
+    for _ in range(warmup):
+        accum.zero_()
+        world_obj.render_device(cam, params, accum.data_ptr(), stream, None)
+    torch.cuda.synchronize()
+    kernel_ms, last = [], None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        accum.zero_()
+        last = rt.rt_stats()
+        world_obj.render_device(cam, params, accum.data_ptr(), stream, last)
+        kernel_ms.append(last.kernel_ms)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, kernel_ms, last
+
+
+def extra_configs(torch, rt, main_world, local_rank):
+    """Short single-GPU runs of the other BASELINE configurations (1 warm-up + 2 steps each)."""
+    out = []
+    cases = [
+        ("c2 at 128 spp (one GPU's share of 1024 spp split over 8)", "book1", 1920, 1080, 128, "book"),
+        ("c2 at 16 spp", "book1", 1920, 1080, 16, "book"),
+        ("c3: book-2 scene, moving spheres", "book2", 1920, 1080, 1024, "book"),
+        ("c4 frame on one GPU: 3840x2160 at 512 spp (one GPU's share of 4096 split over 8)", "book1", 3840, 2160, 512, "book"),
+        ("c5: 10^6 spheres, 64 spp", "stress:1000000", 1920, 1080, 64, CONFIGS["c5"]["camera"]),
+        ("c5: 10^6 spheres, 8 spp (one GPU's share of 64 split over 8)", "stress:1000000", 1920, 1080, 8, CONFIGS["c5"]["camera"]),
+    ]
+    worlds = {"book1": (main_world, None)}
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, scene, nx, ny, spp, cam_spec in cases:
+        if scene not in worlds:
+            t0 = time.perf_counter()
+            path = scene_file(rt, scene)
+            t_gen = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            worlds[scene] = (rt.World(path, device=local_rank), {"recipe_s": t_gen, "build_upload_s": time.perf_counter() - t0})
+            if scene.startswith("stress:"):
+                os.unlink(path)
+        w, setup = worlds[scene]
+        cam = rt.camera(camera15(cam_spec, nx / ny))
+        accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")
+        params = w.params(nx, ny, 0, spp, seed=1, accum=rt.RT_ACCUM_F32)
+        wall, kms, last = run_steps(torch, w, cam, params, accum, stream, 2, 1)
+        paths = nx * ny * spp
+        rec = {"config": name, "scene": scene, "nx": nx, "ny": ny, "spp": spp, "value": paths * 2 / wall / 1e6, "unit": "Mpaths/s",
+               "ms_per_step": wall / 2 * 1e3, "kernel_ms": float(np.mean(kms)), "rays_per_path": last.rays / last.paths,
+               "mean_radiance": float(accum.mean().item()) / spp}
+        if setup:
+            rec["setup_s"] = setup
+        out.append(rec)
+        del accum
+    for scene, (w, setup) in worlds.items():
+        if setup is not None:
+            w.close()
+    return out
 
 
 def main():
@@ -132,15 +257,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="book1", help="recipe name under tests/golden/scenes or a recipe path")
-    ap.add_argument("--nx", type=int, default=1920)
-    ap.add_argument("--ny", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="a BASELINE.json configuration; explicit flags override its fields")
+    ap.add_argument("--scene", default=None, help="recipe name under tests/golden/scenes, a recipe path, or stress:N")
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--ny", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU per step (weak scaling)")
+    ap.add_argument("--total-spp", type=int, default=None, help="samples per pixel per step in all, split across the GPUs (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configurations")
+    ap.add_argument("--timed-only", action="store_true", help="profiling runs: nothing but the warm-up and the timed steps touches the GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
-    ap.add_argument("--camera", default="book", help="book (main.cpp:114-120) or 'fx,fy,fz,ax,ay,az,vfov'")
+    ap.add_argument("--camera", default=None, help="book (main.cpp:114-120) or 'fx,fy,fz,ax,ay,az,vfov'")
+    ap.add_argument("--dump-accum", default=None, help="rank 0 writes the reduced float sums of the last step to this .npy file")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config or "c2"])
+    for k in ("scene", "nx", "ny", "camera"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    if args.total_spp is not None:
+        cfg["total_spp"], cfg["spp"] = args.total_spp, None
+    elif args.spp is not None:
+        cfg["spp"], cfg["total_spp"] = args.spp, None
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_extra = True
+    scene, nx, ny = cfg["scene"], cfg["nx"], cfg["ny"]
+    strong = cfg["total_spp"] is not None
 
     import torch
     import torch.distributed as dist
@@ -160,26 +302,19 @@ def main():
             dist.init_process_group(args.backend)
 
     rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
-    if args.scene.startswith("stress:"):          # e.g. stress:1000000 -- generated on the fly (configs[4])
-        import tempfile
-        scene_path = os.path.join(tempfile.gettempdir(), f"rtiow_{args.scene.replace(':', '_')}_{os.getpid()}.recipe")
-        rt.generate("stress", 1, scene_path, n=int(args.scene.split(":")[1]))
-    else:
-        scene_path = args.scene if os.path.exists(args.scene) else os.path.join(SCENES, args.scene + ".recipe")
-    cam15 = book_camera(args.nx / args.ny)
-    if args.camera != "book":
-        v = [float(x) for x in args.camera.split(",")]
-        cam15[0:6] = v[0:6]
-        cam15[9] = v[6]
+    scene_path = scene_file(rt, scene)
+    cam15 = camera15(cfg["camera"], nx / ny)
     t_build = time.perf_counter()
     w = rt.World(scene_path, device=local_rank)
     t_build = time.perf_counter() - t_build
     cam = rt.camera(cam15)
 
-    accum = torch.zeros(args.ny, args.nx, 3, dtype=torch.float32, device="cuda")
+    accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    s_begin, s_end = sample_range(rank, args.spp)
-    params = w.params(args.nx, args.ny, s_begin, s_end, seed=1, accum=rt.RT_ACCUM_F32)
+    s_begin, s_end = sample_range(rank, cfg["spp"], world, cfg["total_spp"])
+    my_spp = s_end - s_begin
+    frame_spp = cfg["total_spp"] if strong else cfg["spp"] * world
+    params = w.params(nx, ny, s_begin, s_end, seed=1, accum=rt.RT_ACCUM_F32)
     kernel_ms = []
 
     def step(record):
@@ -187,7 +322,7 @@ def main():
         stats = rt.rt_stats() if record else None
         w.render_device(cam, params, accum.data_ptr(), stream, stats)
         if world > 1:
-            dist.all_reduce(accum)          # RCCL sum over xGMI
+            dist.all_reduce(accum)          # RCCL sum over xGMI, ordered after the render on the same stream
         if record:
             kernel_ms.append(stats.kernel_ms)
             return stats
@@ -212,46 +347,68 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    paths_per_step = args.nx * args.ny * args.spp * world
+    paths_per_step = nx * ny * frame_spp
     value = paths_per_step * args.steps / elapsed / 1e6
-    mean = float(accum.mean().item()) / (args.spp * world)
+    mean = float(accum.mean().item()) / frame_spp
+    if rank == 0 and args.dump_accum:
+        np.save(args.dump_accum, accum.cpu().numpy())
 
     if rank == 0:
         counts = algorithmic_counts(scene_path, cam15)
         bytes_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 32 + counts["sphere_tests_per_ray"] * 16 +
-                                                    counts["moving_tests_per_ray"] * 40) + 12.0 / args.spp
+                                                    counts["moving_tests_per_ray"] * 40) + 12.0 / max(1, my_spp)
         flops_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 27 + (counts["sphere_tests_per_ray"] +
                                                     counts["moving_tests_per_ray"]) * 30 + 60)
         k_s = float(np.mean(kernel_ms)) / 1e3
-        launch_paths = args.nx * args.ny * args.spp
-        achieved = launch_paths * bytes_per_path / k_s / 1e9
-        # HBM bytes of one k_render launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE
-        # doubled for gfx950 + WRITE_SIZE); only valid for the configuration it was collected on
+        launch_paths = nx * ny * my_spp
+        alg_gbs = launch_paths * bytes_per_path / k_s / 1e9
+        config_key = f"{scene} {nx}x{ny} samples [{s_begin},{s_end})"
+        # HBM bytes of one launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE doubled for
+        # gfx950 + WRITE_SIZE); only valid for the configuration it was collected on
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (args.scene, args.nx, args.ny, args.spp) == ("book1", 1920, 1080, 1024):
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("config_key") == config_key:
+                traffic = tj["hbm_bytes_per_launch"]
+        algorithmic_hbm = {"what": "REFERENCE-traversal bytes (32 B per box test, 16 B per static-sphere test, 40 B per moving-sphere test, 12 B of "
+                                   "framebuffer per pixel; counts of the reference's both-children walk measured by the oracle) / kernel time, against HBM "
+                                   "peak: reference-work-equivalents that this kernel neither fetches (the tree is in LDS) nor executes; may exceed 1",
+                           "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+                           "algorithmic_bytes_per_launch": launch_paths * bytes_per_path, "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,
+                           "reference_flops": {"achieved_tflops": launch_paths * flops_per_path / k_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
+                                               "frac": launch_paths * flops_per_path / k_s / 1e12 / FP64_PEAK_TFLOPS}}
+        roofline = valu_roofline(config_key, k_s)
+        if roofline is None:   # no PMC pass on file for this configuration: only the measured HBM side can be stated
+            roofline = {"bound": "valu", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                        "meaning": f"no PMC pass over '{config_key}' in profiles/valu.json (tools/profile_round.sh collects it for the default configuration)"}
+        roofline.update({"traffic": traffic, "traffic_unit": "HBM bytes per step: costing pass + main launch (PMC, profiles/traffic.json)",
+                         "hbm_frac": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "kernel": "k_render (+ its costing pass and tile sort)", "kernel_ms": k_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms], "algorithmic_hbm": algorithmic_hbm})
+        metric = "Mpaths/s at 1080p random-spheres" if (nx, ny) == (1920, 1080) else f"Mpaths/s at {nx}x{ny} random-spheres"
         line = {
-            "metric": "Mpaths/s at 1080p random-spheres", "value": value, "unit": "Mpaths/s", "n_gpus": world,
+            "metric": metric, "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{WORKLOADS.get(args.scene.split(':')[0], args.scene)} [{args.scene}] ({args.nx}x{args.ny}, "
-                                   f"{args.spp} spp per GPU per step, max depth 50, BVH built by the reference algorithm)",
-                       "nx": args.nx, "ny": args.ny, "spp_per_gpu": args.spp, "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{WORKLOADS.get(scene.split(':')[0], scene)} [{scene}] ({nx}x{ny}, "
+                                   + (f"{frame_spp} spp per step split across {world} GPU(s)" if strong else f"{cfg['spp']} spp per GPU per step")
+                                   + ", max depth 50, BVH built by the reference algorithm)",
+                       "nx": nx, "ny": ny, "spp_per_gpu": my_spp, "spp_per_frame": frame_spp,
+                       "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
             "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per step: costing pass + main launch (PMC, profiles/traffic.json)",
-                         "algorithmic_bytes_per_launch": launch_paths * bytes_per_path, "kernel": "k_render<float, lds_tree, 4 waves> (+ its costing pass and tile sort)", "kernel_ms": k_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms],
-                         "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,
-                         "valu_f64": {"achieved_tflops": launch_paths * flops_per_path / k_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
-                                      "frac": launch_paths * flops_per_path / k_s / 1e12 / FP64_PEAK_TFLOPS}},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene_path, cam15, args.nx, args.ny)
-        if world == 1:
-            line["image_check"] = image_check(rt, w, args.scene)
+            line["cpu_baseline"] = cpu_baseline(scene_path, cam15, nx, ny)
+        if world == 1 and not args.timed_only:
+            line["image_check"] = image_check(rt, w, scene)
+        if world == 1 and not args.no_extra:
+            line["extra_configs"] = extra_configs(torch, rt, w, local_rank)
         print(json.dumps(line), flush=True)
     w.close()
+    if scene.startswith("stress:"):
+        os.unlink(scene_path)
     if world > 1:
         dist.destroy_process_group()
 

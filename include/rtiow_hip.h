@@ -10,7 +10,8 @@
  * function returns 0 on success and a non-zero RT_E_* code on failure, with the
  * message available from rt_last_error() (thread-local).  No exceptions cross the
  * boundary.  A scene lives on one GPU (chosen at rt_scene_create); one host thread
- * or process per GPU may use its own scenes concurrently.
+ * or process per GPU may use its own scenes concurrently.  Wherever a function takes a
+ * `device`, -1 stands for the calling thread's current HIP device.
  *
  * All arithmetic is IEEE double precision, evaluated in the reference's operation
  * order without fused multiply-add, so hit/miss decisions, primitive ids, t, p and
@@ -147,7 +148,7 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 
-/* Same, into a host buffer that is zeroed first (allocates and frees device memory). */
+/* Same as rt_render, into a host buffer that is zeroed first (allocates and frees device memory). */
 int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
                    void *accum_host, rt_stats *stats);
 

@@ -7,7 +7,8 @@ with a fixed numpy seed; the expected outputs come from the reference's own clas
 The reference holds no golden vectors of its own (it has no tests), so these captures
 are what pins the oracle and the GPU path.
 
-Usage: python oracle/make_goldens.py        (from the repository root)
+Usage: python oracle/make_goldens.py                  (from the repository root; everything)
+       python oracle/make_goldens.py --deep-frames    (only tests/golden/frames_1024.npz)
 """
 import ctypes
 import json
@@ -139,9 +140,39 @@ def trace(tmp, scene, rays, tmin, tmax):
     return get(rout, 9)
 
 
+def deep_frames():
+    """400x200 frames at 1024 samples per pixel from the reference, two seeds per scene, rendered
+    by concurrent single-threaded processes (about 2-5 minutes each): the noise floor between the
+    two seeds is then ~0.005 in linear radiance, so a bias of a few 1e-4 in the GPU's image shows."""
+    cam2 = book_camera(2.0)
+    frames = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        jobs = []
+        for scene in ["two_perlin", "book1", "book2"]:
+            for seed in (1, 2):
+                img = os.path.join(tmp, f"{scene}_{seed}.bin")
+                cmd = [REF, "render", os.path.join(SCENES, scene + ".recipe"), seed, 400, 200, 1024, *cam2, img]
+                jobs.append((scene, seed, img, subprocess.Popen([str(c) for c in cmd], stdout=subprocess.DEVNULL)))
+        for scene, seed, img, proc in jobs:
+            if proc.wait():
+                raise RuntimeError(f"reference render of {scene} seed {seed} failed")
+            frames[f"{scene}_spp1024_seed{seed}"] = get(img, 3).reshape(200, 400, 3).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "frames_1024.npz"), camera=np.array(cam2), **frames)
+    return {k: list(v.shape) for k, v in frames.items()}
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_capture is missing: run `make -C oracle` where /root/reference exists")
+    if sys.argv[1:] == ["--deep-frames"]:      # only the 1024-spp frames (the slow part), leaving the rest as committed
+        shapes = deep_frames()
+        path = os.path.join(GOLD, "manifest.json")
+        manifest = json.load(open(path))
+        manifest["frames_1024"] = shapes
+        with open(path, "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print(json.dumps(shapes))
+        return
     write_scenes()
     rng = np.random.default_rng(20250829)
     manifest = {}
@@ -266,6 +297,7 @@ def main():
                 frames[f"{scene}_spp256_seed{seed}"] = get(img, 3).reshape(60, 120, 3).astype(np.float32)
         np.savez_compressed(os.path.join(GOLD, "frames.npz"), camera=np.array(cam2), **frames)
         manifest["frames"] = {k: list(v.shape) for k, v in frames.items()}
+    manifest["frames_1024"] = deep_frames()
 
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -218,7 +218,7 @@ def world_tables(recipe_path):
         host().rth_world_free(h)
 
 
-def aabb_hit_batch(cases, device=0):
+def aabb_hit_batch(cases, device=-1):
     """aabb::hit; cases[n,14] = box min(3) max(3), ray origin(3) direction(3), tmin, tmax."""
     c = np.ascontiguousarray(cases, dtype=np.float64)
     n = len(c)
@@ -230,7 +230,7 @@ def aabb_hit_batch(cases, device=0):
     return out
 
 
-def camera_batch(cam, st, tape, device=0):
+def camera_batch(cam, st, tape, device=-1):
     st = np.ascontiguousarray(st, dtype=np.float64)
     tape = np.ascontiguousarray(tape, dtype=np.float64)
     n, k = len(st), tape.shape[1]
@@ -245,7 +245,7 @@ def camera_batch(cam, st, tape, device=0):
 class World:
     """A recipe's world, built through the host scene API and resident on one GPU."""
 
-    def __init__(self, recipe_path, device=0):
+    def __init__(self, recipe_path, device=-1):
         self._h = ctypes.c_void_p()
         self.device = device
         if host().rth_world_load(recipe_path.encode(), device, ctypes.byref(self._h)):

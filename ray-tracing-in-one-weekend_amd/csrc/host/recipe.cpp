@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -61,6 +62,54 @@ void recipe::save(std::string const& path) const {
     std::fclose(f);
 }
 
+namespace {
+// the numbers after a line's keyword: an integer, then `n` doubles (strtod, a fraction of the
+// cost of a scanf format over the whole line, which matters for scenes of 10^6 spheres)
+char const* skip_word(char const* s) {
+    while (*s == ' ' || *s == '\t') ++s;
+    while (*s && *s != ' ' && *s != '\t' && *s != '\n' && *s != '\r') ++s;
+    return s;
+}
+
+// `n` doubles after the first `words` words of the line
+bool doubles_after(char const* s, int words, double* out, int n) {
+    for (int k = 0; k < words; ++k) s = skip_word(s);
+    for (int k = 0; k < n; ++k) {
+        char* end;
+        out[k] = std::strtod(s, &end);
+        if (end == s) return false;
+        s = end;
+    }
+    return true;
+}
+
+bool second_word(char const* s, char* out, size_t cap) {
+    s = skip_word(s);
+    while (*s == ' ' || *s == '\t') ++s;
+    char const* e = skip_word(s);
+    size_t const n = (size_t)(e - s);
+    if (n == 0 || n >= cap) return false;
+    std::memcpy(out, s, n);
+    out[n] = 0;
+    return true;
+}
+
+bool int_and_doubles(char const* s, int* first, double* out, int n) {
+    s = skip_word(s);   // the keyword
+    char* end;
+    long const v = std::strtol(s, &end, 10);
+    if (end == s) return false;
+    *first = (int)v;
+    s = end;
+    for (int k = 0; k < n; ++k) {
+        out[k] = std::strtod(s, &end);
+        if (end == s) return false;
+        s = end;
+    }
+    return true;
+}
+}  // namespace
+
 recipe recipe::load(std::string const& path) {
     std::FILE* f = std::fopen(path.c_str(), "r");
     if (!f) throw std::runtime_error("cannot open " + path);
@@ -75,7 +124,15 @@ recipe recipe::load(std::string const& path) {
     };
     while (std::fgets(line, sizeof line, f)) {
         ++lineno;
-        if (std::sscanf(line, "%63s", kw) != 1 || kw[0] == '#') continue;
+        {   // the first word
+            char const* b = line;
+            while (*b == ' ' || *b == '\t') ++b;
+            char const* e = skip_word(b);
+            size_t const n = (size_t)(e - b);
+            if (n == 0 || n >= sizeof kw || *b == '#') continue;
+            std::memcpy(kw, b, n);
+            kw[n] = 0;
+        }
         if (!header) {
             int ver = 0;
             if (std::strcmp(kw, "rtiow-recipe") != 0 || std::sscanf(line, "%*s %d", &ver) != 1 || ver != 1) bad("not a version-1 recipe");
@@ -84,10 +141,10 @@ recipe recipe::load(std::string const& path) {
         }
         if (!std::strcmp(kw, "texture")) {
             tex t{};
-            if (std::sscanf(line, "%*s %63s", sub) != 1) bad("texture kind missing");
+            if (!second_word(line, sub, sizeof sub)) bad("texture kind missing");
             if (!std::strcmp(sub, "constant")) {
                 t.kind = RT_TEX_CONSTANT;
-                if (std::sscanf(line, "%*s %*s %lf %lf %lf", &t.c[0], &t.c[1], &t.c[2]) != 3) bad("constant texture needs R G B");
+                if (!doubles_after(line, 2, t.c, 3)) bad("constant texture needs R G B");
             } else if (!std::strcmp(sub, "chequer")) {
                 t.kind = RT_TEX_CHEQUER;
                 if (std::sscanf(line, "%*s %*s %d %d", &t.even, &t.odd) != 2) bad("chequer texture needs EVEN ODD");
@@ -98,13 +155,17 @@ recipe recipe::load(std::string const& path) {
             rc.textures.push_back(t);
         } else if (!std::strcmp(kw, "material")) {
             mat m{};
-            if (std::sscanf(line, "%*s %63s", sub) != 1) bad("material kind missing");
+            if (!second_word(line, sub, sizeof sub)) bad("material kind missing");
             if (!std::strcmp(sub, "lambertian")) {
                 m.kind = RT_MAT_LAMBERTIAN;
-                if (std::sscanf(line, "%*s %*s %d", &m.tex) != 1 || m.tex < 0 || m.tex >= (int)rc.textures.size()) bad("lambertian needs a texture");
+                double v;
+                if (!doubles_after(line, 2, &v, 1) || v < 0 || v >= (double)rc.textures.size() || v != (double)(int)v) bad("lambertian needs a texture");
+                m.tex = (int)v;
             } else if (!std::strcmp(sub, "metal")) {
                 m.kind = RT_MAT_METAL;
-                if (std::sscanf(line, "%*s %*s %lf %lf %lf %lf", &m.albedo[0], &m.albedo[1], &m.albedo[2], &m.fuzz) != 4) bad("metal needs R G B FUZZ");
+                double v[4];
+                if (!doubles_after(line, 2, v, 4)) bad("metal needs R G B FUZZ");
+                m.albedo[0] = v[0]; m.albedo[1] = v[1]; m.albedo[2] = v[2]; m.fuzz = v[3];
             } else if (!std::strcmp(sub, "dielectric")) {
                 m.kind = RT_MAT_DIELECTRIC;
                 if (std::sscanf(line, "%*s %*s %lf", &m.ri) != 1) bad("dielectric needs RI");
@@ -114,14 +175,17 @@ recipe recipe::load(std::string const& path) {
             prim p{};
             if (kw[0] == 's') {
                 p.kind = RT_PRIM_SPHERE;
-                if (std::sscanf(line, "%*s %d %lf %lf %lf %lf", &p.mat, &p.c0[0], &p.c0[1], &p.c0[2], &p.r) != 5) bad("sphere needs MAT CX CY CZ R");
+                double v[4];
+                if (!int_and_doubles(line, &p.mat, v, 4)) bad("sphere needs MAT CX CY CZ R");
+                p.c0[0] = v[0]; p.c0[1] = v[1]; p.c0[2] = v[2]; p.r = v[3];
                 std::memcpy(p.c1, p.c0, sizeof p.c0);
                 p.t0 = 0; p.t1 = 1;
             } else {
                 p.kind = RT_PRIM_MOVING_SPHERE;
-                if (std::sscanf(line, "%*s %d %lf %lf %lf %lf %lf %lf %lf %lf %lf", &p.mat, &p.c0[0], &p.c0[1], &p.c0[2], &p.c1[0],
-                                &p.c1[1], &p.c1[2], &p.t0, &p.t1, &p.r) != 10)
-                    bad("moving_sphere needs MAT C0 C1 T0 T1 R");
+                double v[9];
+                if (!int_and_doubles(line, &p.mat, v, 9)) bad("moving_sphere needs MAT C0 C1 T0 T1 R");
+                std::memcpy(p.c0, v, sizeof p.c0); std::memcpy(p.c1, v + 3, sizeof p.c1);
+                p.t0 = v[6]; p.t1 = v[7]; p.r = v[8];
             }
             if (p.mat < 0 || p.mat >= (int)rc.materials.size()) bad("material out of range");
             rc.prims.push_back(p);

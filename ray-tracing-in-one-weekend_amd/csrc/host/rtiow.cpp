@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <future>
+#include <map>
 #include <stdexcept>
 #include <string>
 
@@ -39,7 +41,12 @@ std::vector<double> peek_uniforms(std::mt19937 const& mt, size_t k) {
 
 void advance(std::mt19937& mt, int used) { mt.discard(2ull * (unsigned long long)used); }
 
+int g_probe_device = -1;
+
 }  // namespace
+
+int probe_device() { return g_probe_device; }
+void set_probe_device(int device) { g_probe_device = device; }
 
 // ---------------------------------------------------------------- value types ----
 // vec3.cpp:16-74: component-wise, scalar division divides each component
@@ -75,7 +82,7 @@ bool aabb::hit(ray const& r, double tmin, double tmax) const {
     double const box[6] = {_min.x(), _min.y(), _min.z(), _max.x(), _max.y(), _max.z()};
     rt_ray const rr = to_abi(r);
     uint8_t out = 0;
-    if (rt_aabb_hit_batch(0, box, &rr, &tmin, &tmax, 1, &out)) device_failure("aabb::hit");
+    if (rt_aabb_hit_batch(probe_device(), box, &rr, &tmin, &tmax, 1, &out)) device_failure("aabb::hit");
     return out != 0;
 }
 
@@ -174,7 +181,7 @@ colour texture::value(double, double, vec3 const& p) const {
     if (!probe) {
         probe_material pm(*this);
         probe_object po(pm);
-        probe = std::make_unique<device_scene>(po);
+        probe = std::make_unique<device_scene>(po, probe_device());
     }
     double const in[3] = {p.x(), p.y(), p.z()};
     double out[3];
@@ -228,7 +235,7 @@ material::~material() = default;
 std::optional<scatter_record> material::scatter(ray const& r, hit_record const& hit) const {
     if (!probe) {
         probe_object po(*this);
-        probe = std::make_unique<device_scene>(po);
+        probe = std::make_unique<device_scene>(po, probe_device());
     }
     rt_ray const in = to_abi(r);
     rt_hit h{};
@@ -299,7 +306,7 @@ void object::flatten_items(scene_flattener& out) const {
 }
 
 std::optional<hit_record> object::hit(ray const& r, double t_min, double t_max) const {
-    if (!self_scene) self_scene = std::make_unique<device_scene>(*this);
+    if (!self_scene) self_scene = std::make_unique<device_scene>(*this, probe_device());
     rt_ray const in = to_abi(r);
     rt_hit h;
     if (rt_trace_batch(self_scene->get(), &in, 1, t_min, t_max, &h)) device_failure("object::hit");
@@ -390,37 +397,103 @@ void object_list::flatten_items(scene_flattener& out) const {
 
 std::uniform_int_distribution<int> bvh_node::dist{0, 2};
 
+// How many bvh_node objects the reference's constructor creates over n objects
+// (bvh_node.cpp:31-41: one over one or two objects, else one plus the two halves).
+namespace {
+size_t nodes_over(size_t n, std::map<size_t, size_t>& memo) {
+    if (n <= 2) return 1;
+    auto it = memo.find(n);
+    if (it != memo.end()) return it->second;
+    size_t const c = 1 + nodes_over(n / 2, memo) + nodes_over(n - n / 2, memo);
+    memo[n] = c;
+    return c;
+}
+constexpr size_t kParallelBuildMin = size_t(1) << 14;   // objects under a node worth a thread of its own
+int const kParallelBuildDepth = getenv("RTIOW_BUILD_DEPTH") ? atoi(getenv("RTIOW_BUILD_DEPTH")) : 4;                   // ... down to this depth: at most 16 threads
+}  // namespace
+
+// The reference draws one axis per node from the shared generator, a node's own before its left
+// subtree's, the whole left subtree before the right (bvh_node.cpp:9,39-40): node k in pre-order
+// takes draw k, whatever the objects are.  Drawing all of them up front leaves the generator where
+// the reference leaves it and lets the two halves of a large node be built at the same time.
+struct bvh_node::build_plan {
+    std::vector<uint8_t> axis;            // by pre-order node number
+    std::map<size_t, size_t> node_count;  // nodes_over, for the sizes that occur
+    double t0, t1;
+};
+
+bvh_node::build_plan bvh_node::draw_axes(std::mt19937& mt, size_t n, double t0, double t1) {
+    build_plan plan;
+    plan.t0 = t0; plan.t1 = t1;
+    size_t const nodes = nodes_over(n, plan.node_count);
+    plan.axis.resize(nodes);
+    for (uint8_t& a : plan.axis) a = (uint8_t)dist(mt);
+    return plan;
+}
+
 // bvh_node.cpp:8-50
-bvh_node::bvh_node(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double const t0, double const t1) {
-    int const axis = dist(mt);
+bvh_node::bvh_node(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double const t0, double const t1)
+    : bvh_node(draw_axes(mt, objects.size(), t0, t1), objects, 0, 0) {}
+
+bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object const>> objects, size_t const index, int const depth) {
+    int const axis = plan.axis[index];
+    double const t0 = plan.t0, t1 = plan.t1;
     // The reference sorts the pointers with a comparator that asks both objects for their
     // boxes at every comparison (bvh_node.cpp:9-29).  The outcome of a comparison depends
     // only on the two objects' box minima along the axis, and the permutation a sort produces
     // depends only on the outcomes, so sorting (key, pointer) pairs with the same algorithm
     // gives the same order -- ties and all -- at a fraction of the cost for large scenes.
     if (objects.size() > 1) {
-        struct keyed { double key; std::unique_ptr<object const> ptr; };
-        std::vector<keyed> order;
-        order.reserve(objects.size());
-        for (auto& o : objects) {
+        struct keyed { double key; object const* ptr; };
+        constexpr size_t kSmall = 16;
+        keyed small[kSmall];
+        std::vector<keyed> large;
+        if (objects.size() > kSmall) large.resize(objects.size());
+        std::span<keyed> const order(objects.size() > kSmall ? large.data() : small, objects.size());
+        for (size_t i = 0; i < objects.size(); ++i) {
+            object const* const o = objects[i].get();
             std::optional<aabb> const b = o != nullptr ? o->bounding_box(t0, t1) : std::nullopt;
             if (!b) throw "no bounding box in bvh_node constructor";
             vec3 const lo = b->min();
-            order.push_back(keyed{axis == 0 ? lo.x() : (axis == 1 ? lo.y() : lo.z()), std::move(o)});
+            order[i] = keyed{axis == 0 ? lo.x() : (axis == 1 ? lo.y() : lo.z()), o};
         }
         std::ranges::sort(order, [](keyed const& l, keyed const& r) -> bool { return l.key < r.key; });
-        for (size_t i = 0; i < order.size(); ++i) objects[i] = std::move(order[i].ptr);
+        for (auto& o : objects) (void)o.release();   // every pointer is in `order` now
+        for (size_t i = 0; i < order.size(); ++i) objects[i].reset(order[i].ptr);
     }
 
     assert(objects.size() > 0);
     if (objects.size() == 1) {
-        left = right = std::shared_ptr<object const>(std::move(objects[0]));
+        own_left = std::move(objects[0]);           // one object, both children (bvh_node.cpp:31-34)
+        left = right = own_left.get();
     } else if (objects.size() == 2) {
-        left = std::move(objects[0]);
-        right = std::move(objects[1]);
+        own_left = std::move(objects[0]);
+        own_right = std::move(objects[1]);
+        left = own_left.get(); right = own_right.get();
     } else {
-        left = std::make_unique<bvh_node const>(mt, objects.subspan(0, objects.size() / 2), t0, t1);
-        right = std::make_unique<bvh_node const>(mt, objects.subspan(objects.size() / 2), t0, t1);
+        size_t const half = objects.size() / 2;
+        size_t const left_index = index + 1, right_index = left_index + (half <= 2 ? 1 : plan.node_count.at(half));
+        auto build = [&plan, depth](std::span<std::unique_ptr<object const>> part, size_t at) {
+            return std::unique_ptr<bvh_node const>(new bvh_node(plan, part, at, depth + 1));
+        };
+        if (objects.size() >= kParallelBuildMin && depth < kParallelBuildDepth) {
+            // (an exception from either half -- the reference's string literal -- comes out of here
+            // after both have ended)
+            auto other = std::async(std::launch::async, build, objects.subspan(0, half), left_index);
+            std::unique_ptr<bvh_node const> r;
+            try {
+                r = build(objects.subspan(half), right_index);
+            } catch (...) {
+                other.wait();
+                throw;
+            }
+            own_left = other.get();
+            own_right = std::move(r);
+        } else {
+            own_left = build(objects.subspan(0, half), left_index);
+            own_right = build(objects.subspan(half), right_index);
+        }
+        left = own_left.get(); right = own_right.get();
     }
 
     std::optional<aabb> const box_left = left->bounding_box(t0, t1), box_right = right->bounding_box(t0, t1);
@@ -487,7 +560,7 @@ ray camera::get_ray(double const s, double const t) const {
         std::vector<double> const tape = peek_uniforms(mt, k);
         rt_ray out;
         int32_t used = 0;
-        int const rc = rt_camera_batch(0, &c, st, tape.data(), k, 1, &out, &used);
+        int const rc = rt_camera_batch(probe_device(), &c, st, tape.data(), k, 1, &out, &used);
         if (rc == RT_E_TAPE && k < (1u << 20)) continue;
         if (rc) device_failure("camera::get_ray");
         advance(mt, used);

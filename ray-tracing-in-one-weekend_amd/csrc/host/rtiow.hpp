@@ -100,12 +100,20 @@ public:
     rt_scene_desc desc() const;
 };
 
-// A world resident on one GPU.
+// The GPU used by the per-ray calls that bring no scene of their own -- aabb::hit,
+// camera::get_ray, and the one-object scenes behind object::hit, material::scatter and
+// texture::value.  -1, the default, is the calling thread's current HIP device (device 0
+// unless the program chose another with hipSetDevice), so a process bound to one GPU of a
+// node stays on it.
+int probe_device();
+void set_probe_device(int device);
+
+// A world resident on one GPU (-1: the calling thread's current HIP device).
 class device_scene final {
     rt_scene* handle = nullptr;
     scene_flattener flat;
 public:
-    explicit device_scene(object const& world, int device = 0);
+    explicit device_scene(object const& world, int device = -1);
     ~device_scene();
     device_scene(device_scene const&) = delete;
     device_scene& operator=(device_scene const&) = delete;
@@ -254,8 +262,16 @@ public:
 
 class bvh_node final : public object {
     static std::uniform_int_distribution<int> dist;
-    std::shared_ptr<object const> left, right;
+    // (the reference holds shared_ptrs because a node over one object points at it twice,
+    // bvh_node.hpp:14-15; here the node owns each child once and points at it once or twice)
+    std::unique_ptr<object const> own_left, own_right;
+    object const* left = nullptr;
+    object const* right = nullptr;
     std::optional<aabb> box;
+    // the axis of every node, drawn before the build (see rtiow.cpp)
+    struct build_plan;
+    static build_plan draw_axes(std::mt19937& mt, size_t n, double t0, double t1);
+    bvh_node(build_plan const& plan, std::span<std::unique_ptr<object const>> objects, size_t index, int depth);
 public:
     // Same build as the reference (bvh_node.cpp:8-50): random axis, std::ranges::sort on
     // the box minimum, median split; takes ownership of the objects in the span.  Throws
@@ -295,7 +311,7 @@ struct render_options {
     int max_depth = 50;                // main.cpp:34
     double t_min = 0.001;              // main.cpp:23
     uint64_t seed = 0;
-    int device = 0;
+    int device = -1;                   // -1: the calling thread's current HIP device
 };
 
 struct frame {

@@ -89,6 +89,24 @@ struct DItem { int32_t ref; uint32_t has_box; };
 struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; double inv_ri; double r0sq; };
 struct DTex { uint32_t kind; uint32_t even, odd; uint32_t pad; double c[3]; };
 
+// How far the line of a ray may pass from a sphere that the reference's test (sphere.cpp:9-22) still
+// hits.  The test asks for a positive discriminant b*b - a*c, and the rounding of b, a and c leaves
+// that quantity uncertain by at most 16 ulp of a*L*L, L the distance from the ray's origin to the
+// centre: a sphere of radius r is "hit" by lines passing within sqrt(r*r + 2^-49 L*L) of its centre,
+// i.e. up to min(2^-50 L*L/r, 2^-24.5 L) outside it.  Trees whose leaves are single spheres behind
+// their own boxes (scenes without moving spheres) must let such rays through: every segment widens
+// the boxes it tests by that amount, with L bounded by the distance from its origin to the centre of
+// the box around the static spheres' centres plus that box's half-diagonal, and r by their smallest
+// radius.  The same amount keeps the skip behind the best hit honest in every scene: the point where
+// such a line comes closest to the centre lies outside the sphere's box by at most this slack.  For
+// origins inside a scene like the book's it is far below the boxes' fixed padding; it matters for
+// origins 10^5 radii away and more.  k = 0 (no static sphere in the scene): no widening.
+struct FarSlack {
+    float cx, cy, cz;   // centre of the world's box
+    float h;            // its half-diagonal, rounded up
+    float k;            // 2^-49 / smallest radius, rounded up; 0 = the scene needs none
+};
+
 struct DScene {
     const DNode *nodes;
     const DLeaf *leaves;
@@ -101,6 +119,7 @@ struct DScene {
     uint32_t n_items;
     uint32_t stack_depth;     // entries per lane
     uint32_t recheck_all;     // test switch: treat every postponed box test as failed (see world_closest_voted)
+    FarSlack far;
 };
 
 struct DCamera {
@@ -151,7 +170,7 @@ __device__ __forceinline__ float below(double x) { const float f = (float)x; ret
 __device__ __forceinline__ float above(double x) { const float f = (float)x; return f + __builtin_fabsf(f) * 0x1p-22f; }
 
 
-__device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
+__device__ __forceinline__ RayCtx make_ctx(const Ray &r, const FarSlack &far) {
     RayCtx c;
     c.o = r.o; c.d = r.d; c.time = r.time;
     c.ix = 1.0 / r.d.x; c.iy = 1.0 / r.d.y; c.iz = 1.0 / r.d.z;
@@ -170,8 +189,16 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r) {
     const float all = __builtin_fabsf(c.ixf) + __builtin_fabsf(c.iyf) + __builtin_fabsf(c.izf);
     const float widen = kWidenK * (__builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz)) +
                         (smallest >= 0x1p-100f && all < HUGE_VALF ? 0x1p-100f : HUGE_VALF);
-    c.cnx = cx - widen; c.cny = cy - widen; c.cnz = cz - widen;
-    c.cfx = cx + widen; c.cfy = cy + widen; c.cfz = cz + widen;
+    // the spatial slack of the sphere test for this origin (see FarSlack), per axis in units of t
+    float wx = widen, wy = widen, wz = widen;
+    if (far.k > 0) {
+        const float dx = (float)r.o.x - far.cx, dy = (float)r.o.y - far.cy, dz = (float)r.o.z - far.cz;
+        const float L = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f + 0x1p-20f) + far.h;
+        const float slack = __builtin_fminf(far.k * L * L, 0x1p-23f * L) * (1.0f + 0x1p-20f);   // (NaN or infinite L: infinite)
+        wx += slack * __builtin_fabsf(c.ixf); wy += slack * __builtin_fabsf(c.iyf); wz += slack * __builtin_fabsf(c.izf);
+    }
+    c.cnx = cx - wx; c.cny = cy - wy; c.cnz = cz - wz;
+    c.cfx = cx + wx; c.cfy = cy + wy; c.cfz = cz + wz;
     return c;
 }
 
@@ -553,8 +580,11 @@ __device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim
 
 // One leaf.  First the reference's own test of the leaf's box (aabb.cpp:8-57, in double, with the
 // interval the reference would pass down: bvh_node.cpp:53) -- the walk above it was only
-// conservative; a leaf of static spheres is also skipped when its box starts beyond the best hit.
-// Then its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the next stack entry.
+// conservative.  Then its one or two spheres (sphere.cpp:9-45, moving_sphere.cpp:13-49), then the
+// next stack entry.  (Skipping behind the best hit is left to the node test, whose entry bound
+// carries the margins for the rounding of the reference's roots: a computed root can undercut the
+// exactly computed entry of its own sphere's box by 4e-8 of its value when the ray grazes the sphere,
+// which at an origin 10^6 radii away is a sizeable part of the radius.)
 //
 // `box_now` = false postpones the box test of a leaf of static spheres: its spheres are tried at once
 // and the caller tests the box of the winning leaf only (see world_closest_voted).
@@ -570,7 +600,7 @@ __device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx 
         bool reached = true;
         if (box_now) {
             double entry;
-            reached = box_test_ordered(rec, r, tmin, tmax, entry) && (tv.bp < 0 || entry <= tv.bt);
+            reached = box_test_ordered(rec, r, tmin, tmax, entry);
         }
         if (reached) {
             const uint32_t k = (ref & LEAF_SECOND) ? 1u : 0u;
@@ -584,7 +614,7 @@ __device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx 
         bool reached = true;
         if (box_now || !safe) {
             double entry;
-            reached = box_test_ordered(rec, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
+            reached = box_test_ordered(rec, r, tmin, tmax, entry);
         }
         if (reached) {
             leaf_candidate_lds(rec + 48, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
@@ -604,7 +634,7 @@ __device__ __forceinline__ void leaf_step(const DLeaf *leaves, const DPrim *prim
         double bx[6], entry;
 #pragma unroll
         for (int k = 0; k < 6; ++k) bx[k] = leaves[leaf].box[k];
-        reached = box_test(bx, r, tmin, tmax, entry) && (!safe || tv.bp < 0 || entry <= tv.bt);
+        reached = box_test(bx, r, tmin, tmax, entry);
     }
     if (reached) {
         // the first sphere of the reference: the leaf's first, or its second on its own (a split leaf)
@@ -828,6 +858,18 @@ __device__ __forceinline__ v3 random_in_unit_sphere(StreamRng &g) {
 // material.cpp:10-12
 __device__ __forceinline__ v3 reflect(v3 v, v3 n) { return vsub(v, vmul(n, 2 * vdot(v, n))); }
 
+// x^5 rounded once: the product is carried as an unevaluated sum of two doubles (error below 2^-100
+// of the value) and rounded at the end, which is the correctly rounded result unless the exact value
+// lies within 2^-100 of a rounding boundary -- what a libm pow(x, 5) of 0.5x ulp accuracy returns
+// in all but such cases.  Used where the reference's draws are replayed (material.cpp:29).
+__device__ __forceinline__ double pow5_rounded(double x) {
+    const double h2 = x * x, l2 = __builtin_fma(x, x, -h2);
+    const double p4 = h2 * h2, e4 = __builtin_fma(h2, h2, -p4) + 2 * (h2 * l2);
+    const double h4 = p4 + e4, l4 = e4 - (h4 - p4);
+    const double p5 = h4 * x, e5 = __builtin_fma(h4, x, -p5) + l4 * x;
+    return p5 + e5;
+}
+
 // material.cpp:47-98.  Returns whether the ray scatters; the draws happen either way.
 template <class R>
 __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ray &r, v3 p, v3 n, R &g, v3 &att, Ray &out) {
@@ -869,10 +911,12 @@ __device__ __forceinline__ bool scatter(const DScene &sc, uint32_t mat, const Ra
     if (disc > 0) {
         refracted = vsub(vmul(vsub(uv, vmul(outward, dt)), ni_over_nt), vmul(outward, sqrt(disc)));
         const double r1 = m->r0sq;
-        // schlick (material.cpp:26-30).  pow(x, 5) is taken by repeated multiplication: at most
-        // 2 ulp from a correctly rounded pow, and the value is only compared with a uniform.
+        // schlick (material.cpp:26-30).  On a path's own stream pow(x, 5) is taken by repeated
+        // multiplication: at most 2 ulp from a correctly rounded pow, and the value is only compared
+        // with a uniform of that stream.  Where the caller's draws are replayed the comparison must
+        // fall as the reference's does, and the power is rounded once, as libm rounds it.
         const double x = 1 - cosine, x2 = x * x;
-        reflect_prob = r1 + (1 - r1) * (x2 * x2 * x);
+        reflect_prob = r1 + (1 - r1) * (R::kMaySkipDeadDraws ? x2 * x2 * x : pow5_rounded(x));
     }
     att = mk(1, 1, 1);
     out.d = g.canonical() < reflect_prob ? reflected : refracted;   // dist{0, 1}: u * 1 + 0 = u

@@ -9,12 +9,16 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <future>
+#include <thread>
 #include <memory>
 #include <new>
 #include <vector>
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_batch(DScene sc, const rt_ray 
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Ray r = load_ray(rays + i);
-    RayCtx ctx = make_ctx(r);
+    RayCtx ctx = make_ctx(r, sc.far);
     double t;
     int prim;
     rt_hit h;
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(kBlock) void k_aabb_batch(const double *boxes, cons
                                                       const double *tmax, size_t n, uint8_t *out) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    RayCtx ctx = make_ctx(load_ray(rays + i));
+    const FarSlack none = {0, 0, 0, 0, 0};
+    RayCtx ctx = make_ctx(load_ray(rays + i), none);
     const double *b = boxes + i * 6;
     double bx[6] = {b[0], b[3], b[1], b[4], b[2], b[5]};
     double entry;
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // entries spill to it.
 constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
 constexpr size_t kCameraLds = 192;            // the block's copy of the camera
+constexpr size_t kHeadLds = kCameraLds + 32;  // ... followed by the scene's FarSlack
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 #ifdef RT_LANE_STATS
 constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics slots per wave of up to 1024 blocks
@@ -163,14 +169,16 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // LDS: [camera][tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][leaves]
+    // LDS: [camera][far slack][tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][leaves]
     // The camera's 24 doubles are needed once per path; as kernel arguments they would sit in 48
     // scalar registers for the whole kernel and push other scalars out into vector-register lanes,
     // to be fetched back with vector instructions in the middle of the hot loops.
     static_assert(sizeof(DCamera) == kCameraLds, "camera copy in LDS");
     if (tid < kCameraLds / sizeof(double)) reinterpret_cast<double *>(lds_raw)[tid] = reinterpret_cast<const double *>(&cam_arg)[tid];
-    double *tile_sum = reinterpret_cast<double *>(lds_raw + kCameraLds) + wave * 192;
-    char *const stacks = lds_raw + kCameraLds + kRenderWaves * 192 * sizeof(double);
+    static_assert(sizeof(FarSlack) == 20 && kHeadLds - kCameraLds >= sizeof(FarSlack), "far slack copy in LDS");
+    if (tid < sizeof(FarSlack) / sizeof(float)) reinterpret_cast<float *>(lds_raw + kCameraLds)[tid] = reinterpret_cast<const float *>(&sc.far)[tid];
+    double *tile_sum = reinterpret_cast<double *>(lds_raw + kHeadLds) + wave * 192;
+    char *const stacks = lds_raw + kHeadLds + kRenderWaves * 192 * sizeof(double);
     char *ltree = stacks + (size_t)stack_cap * kRenderBlock * sizeof(int);
     const LaneStack st = {reinterpret_cast<int *>(stacks) + tid, kRenderBlock, (int)stack_cap,
                           spill ? spill + (size_t)blockIdx.x * kRenderBlock + tid : nullptr, (int)(gridDim.x * kRenderBlock)};
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
             lane_stats.add(2, (uint32_t)__popcll(__ballot(alive)));
             if (want != 0) lane_stats.add(5, (uint32_t)__popcll(want));
             if (alive) {
-                const RayCtx ctx = make_ctx(r);
+                const RayCtx ctx = make_ctx(r, *reinterpret_cast<const FarSlack *>(lds_raw + kCameraLds));
                 double t;
                 int prim;
                 ++nrays;
@@ -405,6 +413,20 @@ template <class T> struct dev_buf {
 
 unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
+// A device argument of -1 stands for the calling thread's current HIP device.
+int use_device(int device, int *chosen) {
+    if (device < 0) {
+        HIP_TRY(hipGetDevice(&device));
+    } else {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_E_DEVICE, "no HIP device available");
+        if (device >= ndev) return fail(RT_E_INVALID, "device %d out of range (have %d)", device, ndev);
+        HIP_TRY(hipSetDevice(device));
+    }
+    if (chosen) *chosen = device;
+    return RT_OK;
+}
+
 }  // namespace
 
 struct rt_scene {
@@ -422,6 +444,7 @@ struct rt_scene {
     std::vector<uint32_t> material_of_prim;  // by description index
     uint32_t n_prims_desc = 0, n_textures = 0;
     dev_buf<int> spill;                      // stack entries beyond the LDS part, per render lane
+    size_t spill_ints = 0;
     dev_buf<uint32_t> tiles;                 // per tile: measured cost, then the render order
     size_t tiles_capacity = 0;
     size_t lds_bytes = 0;                    // stacks of the batch kernels
@@ -584,30 +607,77 @@ struct flattener {
     }
     static void empty_box(double *b) { for (int a = 0; a < 3; ++a) { b[2 * a] = HUGE_VAL; b[2 * a + 1] = -HUGE_VAL; } }
 
-    // binned surface-area heuristic over leaves[first, first+count); returns the split position
-    size_t split(size_t first, size_t count) {
-        constexpr int BINS = 32;
+    // binned surface-area heuristic over leaves[first, first+count); returns the split position.
+    // Large ranges are binned by several threads, each over a slice of the range: bin boxes and
+    // counts are unions and sums, which come out the same in any order.
+    static constexpr int BINS = 32;
+    struct bin_set {
+        double box[3][BINS][6];
+        size_t n[3][BINS];
+        void clear() {
+            for (int a = 0; a < 3; ++a)
+                for (int k = 0; k < BINS; ++k) { empty_box(box[a][k]); n[a][k] = 0; }
+        }
+    };
+    static constexpr size_t kParallelRange = (size_t)1 << 16;   // leaves in a range worth more than one thread
+    static constexpr int kMaxThreads = 16;
+
+    static int bin_of(const double *b, int a, double lo, double ext) {
+        int k = (int)((0.5 * (b[2 * a] + b[2 * a + 1]) - lo) / ext * BINS);
+        return k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
+    }
+
+    // runs f(slice_begin, slice_end, slice_number) over [first, first+count) cut into `slices` pieces
+    template <class F> static void for_slices(size_t first, size_t count, int slices, F f) {
+        std::vector<std::future<void>> jobs;
+        for (int t = 1; t < slices; ++t)
+            jobs.push_back(std::async(std::launch::async, f, first + count * (size_t)t / slices, first + count * (size_t)(t + 1) / slices, t));
+        f(first, first + count / slices, 0);
+        for (auto &j : jobs) j.get();
+    }
+
+    size_t split(size_t first, size_t count, int threads) {
+        const int slices = count >= kParallelRange ? std::max(1, std::min(threads, kMaxThreads)) : 1;
         double cb[6];
         empty_box(cb);
-        for (size_t i = first; i < first + count; ++i) {
-            const double *b = leaves[i].box;
-            for (int a = 0; a < 3; ++a) { const double c = 0.5 * (b[2 * a] + b[2 * a + 1]); cb[2 * a] = std::fmin(cb[2 * a], c); cb[2 * a + 1] = std::fmax(cb[2 * a + 1], c); }
+        {
+            std::vector<std::array<double, 6>> part((size_t)slices);
+            for_slices(first, count, slices, [&](size_t b0, size_t b1, int t) {
+                double *c = part[(size_t)t].data();
+                empty_box(c);
+                for (size_t i = b0; i < b1; ++i) {
+                    const double *b = leaves[i].box;
+                    for (int a = 0; a < 3; ++a) { const double m = 0.5 * (b[2 * a] + b[2 * a + 1]); c[2 * a] = std::fmin(c[2 * a], m); c[2 * a + 1] = std::fmax(c[2 * a + 1], m); }
+                }
+            });
+            for (const auto &c : part) grow(cb, c.data());
         }
+        bool usable[3];
+        for (int a = 0; a < 3; ++a) { const double ext = cb[2 * a + 1] - cb[2 * a]; usable[a] = ext > 0 && std::isfinite(ext); }
+        std::vector<bin_set> part((size_t)slices);
+        for_slices(first, count, slices, [&](size_t b0, size_t b1, int t) {
+            bin_set &bs = part[(size_t)t];
+            bs.clear();
+            for (size_t i = b0; i < b1; ++i) {
+                const double *b = leaves[i].box;
+                for (int a = 0; a < 3; ++a) {
+                    if (!usable[a]) continue;
+                    const int k = bin_of(b, a, cb[2 * a], cb[2 * a + 1] - cb[2 * a]);
+                    grow(bs.box[a][k], b);
+                    bs.n[a][k]++;
+                }
+            }
+        });
+        bin_set &bins = part[0];
+        for (int t = 1; t < slices; ++t)
+            for (int a = 0; a < 3; ++a)
+                for (int k = 0; k < BINS; ++k) { if (part[(size_t)t].n[a][k]) grow(bins.box[a][k], part[(size_t)t].box[a][k]); bins.n[a][k] += part[(size_t)t].n[a][k]; }
         double best_cost = HUGE_VAL;
         int best_axis = -1, best_bin = 0;
         for (int a = 0; a < 3; ++a) {
-            const double lo = cb[2 * a], ext = cb[2 * a + 1] - lo;
-            if (!(ext > 0) || !std::isfinite(ext)) continue;
-            double bb[BINS][6];
-            size_t bn[BINS] = {0};
-            for (int k = 0; k < BINS; ++k) empty_box(bb[k]);
-            for (size_t i = first; i < first + count; ++i) {
-                const double *b = leaves[i].box;
-                int k = (int)((0.5 * (b[2 * a] + b[2 * a + 1]) - lo) / ext * BINS);
-                k = k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
-                grow(bb[k], b);
-                bn[k]++;
-            }
+            if (!usable[a]) continue;
+            const auto &bb = bins.box[a];
+            const auto &bn = bins.n[a];
             double ra[BINS];
             size_t rn[BINS];
             double acc[6];
@@ -627,45 +697,57 @@ struct flattener {
         if (best_axis < 0) return first + count / 2;   // coincident centres: any split will do
         const int a = best_axis;
         const double lo = cb[2 * a], ext = cb[2 * a + 1] - lo;
-        auto mid = std::partition(leaves.begin() + (long)first, leaves.begin() + (long)(first + count), [&](const leaf_rec &l) {
-            int k = (int)((0.5 * (l.box[2 * a] + l.box[2 * a + 1]) - lo) / ext * BINS);
-            k = k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
-            return k <= best_bin;
-        });
+        auto mid = std::partition(leaves.begin() + (long)first, leaves.begin() + (long)(first + count),
+                                  [&](const leaf_rec &l) { return bin_of(l.box, a, lo, ext) <= best_bin; });
         size_t pos = (size_t)(mid - leaves.begin());
         if (pos == first || pos == first + count) pos = first + count / 2;
         return pos;
     }
 
-    // builds the node over leaves[first, first+count) (count >= 2); out_box receives its exact union box
-    int32_t cluster(size_t first, size_t count, uint32_t depth, double *out_box, bool &safe) {
-        if (depth + 1 > max_depth) max_depth = depth + 1;
+    // Builds the node over leaves[first, first+count) (count >= 2) as nodes[me]; its subtree takes
+    // nodes[me, me + count - 1), numbered in pre-order, so the two halves of a large range can be
+    // built by different threads.  out_box receives the node's exact union box, depth_out the
+    // depth of the deepest node below (this node = `depth` + 1).
+    int32_t cluster(size_t first, size_t count, uint32_t depth, size_t me, int threads, double *out_box, bool &safe, uint32_t &depth_out) {
+        depth_out = depth + 1;
         // a tree this deep means the heuristic keeps peeling single leaves: fall back to halving
-        const size_t pos = depth > 48 ? first + count / 2 : split(first, count);
-        const int me = (int)nodes.size();
-        nodes.emplace_back();
+        const size_t pos = depth > 48 ? first + count / 2 : split(first, count, threads);
         DNode out;
         memset(&out, 0, sizeof out);
-        bool safe_c[2];
+        bool safe_c[2] = {true, true};
         double cb[2][6];   // the children's boxes: exact unions of the reference's leaf boxes
+        uint32_t deep[2] = {0, 0};
         const size_t beg[2] = {first, pos}, cnt[2] = {pos - first, first + count - pos};
-        for (int c = 0; c < 2; ++c) {
+        const size_t at[2] = {me + 1, me + cnt[0]};   // (a half of one leaf takes no node)
+        auto child = [&](int c, int th) {
             if (cnt[c] == 1) {
                 out.child[c] = leaves[beg[c]].ref;
                 memcpy(cb[c], leaves[beg[c]].box, sizeof cb[c]);
                 safe_c[c] = leaves[beg[c]].safe;
             } else {
-                out.child[c] = cluster(beg[c], cnt[c], depth + 1, cb[c], safe_c[c]);
+                out.child[c] = cluster(beg[c], cnt[c], depth + 1, at[c], th, cb[c], safe_c[c], deep[c]);
             }
-            set_child_box(out, c, cb[c]);
+        };
+        if (threads > 1 && std::min(cnt[0], cnt[1]) >= 4096) {
+            // threads in proportion to the halves' sizes
+            int t0 = (int)std::llround((double)threads * (double)cnt[0] / (double)count);
+            t0 = std::max(1, std::min(threads - 1, t0));
+            auto other = std::async(std::launch::async, child, 0, t0);
+            child(1, threads - t0);
+            other.get();
+        } else {
+            child(0, threads);
+            child(1, threads);
         }
+        for (int c = 0; c < 2; ++c) set_child_box(out, c, cb[c]);
         if (safe_c[0]) out.flags |= NF_SAFE0;
         if (safe_c[1]) out.flags |= NF_SAFE1;
         safe = safe_c[0] && safe_c[1];
         memcpy(out_box, cb[0], sizeof cb[0]);
         grow(out_box, cb[1]);
+        depth_out = std::max(depth_out, std::max(deep[0], deep[1]));
         nodes[me] = out;
-        return me;
+        return (int32_t)me;
     }
 
     // Scenes of static spheres only: every leaf of two spheres becomes one more node over two
@@ -749,8 +831,16 @@ struct flattener {
 
     // the whole bvh item rooted at description node `id`, re-clustered
     int32_t build_clustered(int32_t id, bool &safe) {
+        const bool verbose = getenv("RTIOW_VERBOSE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            const auto t1 = std::chrono::steady_clock::now();
+            if (verbose) fprintf(stderr, "rtiow:   %s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+            t0 = t1;
+        };
         leaves.clear();
         collect(id, 0);
+        lap("reference leaves collected");
         if (error) return REF_NONE;
         if (static_scene) {
             // cluster the spheres themselves rather than the reference's pairs of them: the pairs are
@@ -768,10 +858,20 @@ struct flattener {
                 }
             }
             leaves.swap(singles);
+            lap("single-sphere boxes");
         }
         if (leaves.size() == 1) { safe = leaves[0].safe; return leaves[0].ref; }
         double box[6];
-        return cluster(0, leaves.size(), 0, box, safe);
+        const size_t me = nodes.size();
+        if (me + leaves.size() - 1 > ((size_t)1 << 26)) { error = "bvh larger than 2^26 nodes"; return REF_NONE; }
+        nodes.resize(me + leaves.size() - 1);   // a binary tree over n leaves has n - 1 nodes
+        int threads = std::max(1u, std::min<unsigned>(kMaxThreads, std::thread::hardware_concurrency()));
+        if (const char *e = getenv("RTIOW_BUILD_THREADS")) threads = std::max(1, std::min(kMaxThreads, atoi(e)));
+        uint32_t deepest = 0;
+        const int32_t root = cluster(0, leaves.size(), 0, me, threads, box, safe, deepest);
+        max_depth = std::max(max_depth, deepest);
+        lap("surface-area clustering");
+        return root;
     }
 };
 
@@ -833,9 +933,10 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
 
 static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (int rc = check_desc(desc)) return rc;
-    int ndev = rt_device_count();
-    if (ndev <= 0) return fail(RT_E_DEVICE, "no HIP device available");
-    if (device < 0 || device >= ndev) return fail(RT_E_INVALID, "device %d out of range (have %d)", device, ndev);
+    if (device < -1) return fail(RT_E_INVALID, "device %d: want an index, or -1 for the current device", device);
+    const bool verbose = getenv("RTIOW_VERBOSE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto seconds_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
 
     flattener fl;
     // RTIOW_TREE=reference keeps the reference's own topology on the device (for A/B and for the
@@ -865,6 +966,11 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         items.push_back(di);
     }
 
+    const double t_layout = seconds_since(t_start);
+    if (verbose) fprintf(stderr, "rtiow: tree laid out on the host in %.3f s (%zu nodes)\n", t_layout, fl.nodes.size());
+    if (rt_device_count() <= 0) return fail(RT_E_DEVICE, "no HIP device available");
+    if (int rc = use_device(device, &device)) return rc;
+
     std::unique_ptr<rt_scene> owner(new rt_scene);   // freed on every early return
     rt_scene *s = owner.get();
     s->device = device;
@@ -884,7 +990,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     {
         const size_t sums = 192 * sizeof(double);   // per wave
         auto whole_tree = [&](int waves) {
-            return kCameraLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
+            return kHeadLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
                    fl.leaf_boxes.size() * (static_scene ? SLEAF_STRIDE : LLEAF_STRIDE);
         };
         const char *force_waves = getenv("RTIOW_RENDER_WAVES");   // "3" keeps the 768-thread shape (tests)
@@ -905,7 +1011,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             uint32_t cap = std::min<uint32_t>(stack_depth, kSpillStackCap);
             if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(1, atoi(force_cap)));
             s->render_waves = kWavesMax;
-            const size_t base = kCameraLds + 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
+            const size_t base = kHeadLds + 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
             size_t k = std::min(fl.nodes.size(), (kLdsBudget - base - 8) / LNODE_STRIDE);
             if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
             fl.stage_top_levels(k, items);
@@ -949,7 +1055,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         memcpy(perm.data() + 512, desc->perlin_perm_z, 256);
     }
 
-    hipError_t e = hipSetDevice(device);
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
     if (e == hipSuccess) e = s->leaves.upload(fl.leaf_boxes.data(), fl.leaf_boxes.size());
     if (e == hipSuccess) e = s->prims.upload(fl.prims.data(), fl.prims.size());
@@ -960,8 +1066,10 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->perm.upload(perm.data(), perm.size());
     if (e == hipSuccess) e = s->counter.alloc(kCounters);
     if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
-    // the render kernel may ask for more dynamic LDS than the default 64 KiB limit
-    const void *kernels[18] = {
+    s->spill_ints = spill_ints;
+    // the kernels with per-lane stacks may ask for more dynamic LDS than the default 64 KiB limit
+    const void *kernels[19] = {
+        reinterpret_cast<const void *>(&k_trace_batch),
 #define RT_SHAPES(D)                                                                \
     reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, false, D>),    \
     reinterpret_cast<const void *>(&k_render<double, true, kWavesMax, false, D>),   \
@@ -987,6 +1095,26 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     {
         s->render_defer = static_scene;
         s->d.recheck_all = getenv("RTIOW_RECHECK_ALL_LEAVES") ? 1u : 0u;
+    }
+    bool any_static = false;
+    for (const DPrim &p : fl.prims) any_static = any_static || (p.orig >= 0 && p.kind == PK_STATIC);
+    if (any_static) {   // see FarSlack
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL}, r_min = HUGE_VAL;
+        for (const DPrim &p : fl.prims) {
+            if (p.orig < 0 || p.kind != PK_STATIC) continue;
+            for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p.c0[a]); hi[a] = std::fmax(hi[a], p.c0[a]); }
+            r_min = std::fmin(r_min, std::fabs(p.r));
+        }
+        double h2 = 0;
+        for (int a = 0; a < 3; ++a) { const double e = 0.5 * (hi[a] - lo[a]); h2 += e * e; }
+        FarSlack &f = s->d.far;
+        f.cx = (float)(0.5 * (lo[0] + hi[0])); f.cy = (float)(0.5 * (lo[1] + hi[1])); f.cz = (float)(0.5 * (lo[2] + hi[2]));
+        // the centre is rounded to single precision: the half-diagonal makes up for it (2^-22 of the coordinates)
+        const double coarse = 0x1p-22 * (std::fabs(lo[0]) + std::fabs(hi[0]) + std::fabs(lo[1]) + std::fabs(hi[1]) + std::fabs(lo[2]) + std::fabs(hi[2]));
+        f.h = nextafterf((float)((std::sqrt(h2) + coarse) * (1 + 0x1p-20)), HUGE_VALF);
+        f.k = r_min > 0 ? nextafterf((float)(0x1p-49 / r_min * (1 + 0x1p-20)), HUGE_VALF) : HUGE_VALF;
+        if (!(f.k > 0)) f.k = 0x1p-126f;   // (a radius beyond 2^77: the slack is below every other margin, but stay in the widening branch)
+        if (!std::isfinite(f.h) || !std::isfinite(f.cx) || !std::isfinite(f.cy) || !std::isfinite(f.cz)) { f.cx = f.cy = f.cz = 0; f.h = HUGE_VALF; }
     }
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);
     s->n_nodes_dev = (uint32_t)fl.nodes.size();
@@ -1027,7 +1155,7 @@ int rt_aabb_hit_batch(int device, const double *boxes, const rt_ray *rays, const
                       size_t n, uint8_t *out) {
     if (n && (!boxes || !rays || !t_min || !t_max || !out)) return fail(RT_E_INVALID, "rt_aabb_hit_batch: null argument");
     if (n == 0) return RT_OK;
-    HIP_TRY(hipSetDevice(device));
+    if (int rc = use_device(device, nullptr)) return rc;
     dev_buf<double> d_boxes, d_tmin, d_tmax;
     dev_buf<rt_ray> d_rays;
     dev_buf<uint8_t> d_out;
@@ -1113,7 +1241,7 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
                     rt_ray *out, int32_t *used) {
     if (!camera || (n && (!st || !out || !used)) || (n && k && !tape)) return fail(RT_E_INVALID, "rt_camera_batch: null argument");
     if (n == 0) return RT_OK;
-    HIP_TRY(hipSetDevice(device));
+    if (int rc = use_device(device, nullptr)) return rc;
     dev_buf<double> d_st, d_tape;
     dev_buf<rt_ray> d_out;
     dev_buf<int32_t> d_used;
@@ -1131,52 +1259,62 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
     return RT_OK;
 }
 
-int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, void *stream_v,
-              rt_stats *stats) {
-    if (!scene || !camera || !pr || !accum_dev) return fail(RT_E_INVALID, "rt_render: null argument");
-    if (pr->nx == 0 || pr->ny == 0) return fail(RT_E_INVALID, "rt_render: empty image");
-    if ((uint64_t)pr->nx * pr->ny > 0xFFFFFFFFull / 3) return fail(RT_E_INVALID, "rt_render: image too large");
-    if (pr->sample_end < pr->sample_begin) return fail(RT_E_INVALID, "rt_render: sample_end < sample_begin");
-    if (pr->sample_end - pr->sample_begin > (1u << 24)) return fail(RT_E_INVALID, "rt_render: more than 2^24 samples per pixel in one call");
-    if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "rt_render: unknown accum_type %u", pr->accum_type);
-    HIP_TRY(hipSetDevice(scene->device));
-    hipStream_t stream = (hipStream_t)stream_v;
-    struct event_pair {   // destroyed on every return
-        hipEvent_t a = nullptr, b = nullptr;
-        ~event_pair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    } ev;
+// Where one frame keeps its working memory.
+struct frame_memory {
+    unsigned long long *counters;   // kCounters entries
+    uint32_t *tiles;                // tile costs, then the tile order; null = none available
+    size_t tiles_capacity;          // entries
+    int *spill;                     // deep stack entries of trees that are not in LDS whole (null when unused)
+};
+
+static int check_render_args(const char *who, rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev) {
+    if (!scene || !camera || !pr || !accum_dev) return fail(RT_E_INVALID, "%s: null argument", who);
+    if (pr->nx == 0 || pr->ny == 0) return fail(RT_E_INVALID, "%s: empty image", who);
+    if ((uint64_t)pr->nx * pr->ny > 0xFFFFFFFFull / 3) return fail(RT_E_INVALID, "%s: image too large", who);
+    if (pr->sample_end < pr->sample_begin) return fail(RT_E_INVALID, "%s: sample_end < sample_begin", who);
+    if (pr->sample_end - pr->sample_begin > (1u << 24)) return fail(RT_E_INVALID, "%s: more than 2^24 samples per pixel in one call", who);
+    if (pr->accum_type > RT_ACCUM_F64) return fail(RT_E_INVALID, "%s: unknown accum_type %u", who, pr->accum_type);
+    return RT_OK;
+}
+
+// how a frame is cut into tiles and handed to the persistent blocks
+struct frame_plan {
+    uint32_t tile_shift, tiles_x, n_tiles, waves, blocks;
+    bool ordered;
+};
+
+static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) {
+    frame_plan f;
     const uint32_t spp = pr->sample_end - pr->sample_begin;
     // 8x8-pixel tiles fill the 64 lanes with a single sample per pixel; from 4 samples per pixel a
     // 4x4 tile does, and tiles a quarter the size leave a quarter of the imbalance at the end of
     // the frame (measured faster from 8 to 1024 samples, within 2 % at 32).
-    uint32_t tile_shift = spp >= 4 ? 2u : 3u;
-    if (const char *e = getenv("RTIOW_TILE_SHIFT")) tile_shift = std::min(3u, std::max(1u, (uint32_t)atoi(e)));   // 1: 2x2 ... 3: 8x8 (experiments)
-    const uint32_t tile_side = 1u << tile_shift;
-    const uint32_t tiles_x = (pr->nx + tile_side - 1) >> tile_shift, tiles_y = (pr->ny + tile_side - 1) >> tile_shift;
-    const uint32_t n_tiles = tiles_x * tiles_y;
-    const uint32_t waves = 4 * (uint32_t)scene->render_waves;
-    const uint32_t blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (n_tiles + waves - 1) / waves);   // the spill area is sized for n_cus blocks
+    f.tile_shift = spp >= 4 ? 2u : 3u;
+    if (const char *e = getenv("RTIOW_TILE_SHIFT")) f.tile_shift = std::min(3u, std::max(1u, (uint32_t)atoi(e)));   // 1: 2x2 ... 3: 8x8 (experiments)
+    const uint32_t tile_side = 1u << f.tile_shift;
+    f.tiles_x = (pr->nx + tile_side - 1) >> f.tile_shift;
+    f.n_tiles = f.tiles_x * ((pr->ny + tile_side - 1) >> f.tile_shift);
+    f.waves = 4 * (uint32_t)scene->render_waves;
+    f.blocks = std::min<uint32_t>((uint32_t)scene->n_cus, (f.n_tiles + f.waves - 1) / f.waves);   // the spill area is sized for n_cus blocks
     // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
     // the pass traces 1 to 4 samples per pixel without touching the image, under 2 % of the work.
-    const bool ordered = spp >= kOrderMinSamples && n_tiles >= 2 * blocks * waves && !getenv("RTIOW_TILE_ORDER_OFF");
-    if (ordered && scene->tiles_capacity < 2 * (size_t)n_tiles) {   // costs of the 8x8 tiles (at most n_tiles of them), then the order
-        if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
-        HIP_TRY(scene->tiles.alloc(2 * (size_t)n_tiles));
-        scene->tiles_capacity = 2 * (size_t)n_tiles;
-    }
+    f.ordered = spp >= kOrderMinSamples && f.n_tiles >= 2 * f.blocks * f.waves && !getenv("RTIOW_TILE_ORDER_OFF");
+    return f;
+}
+
+// Queues one frame on `stream`: counters cleared, costing pass and tile sort when the plan says so,
+// then the main launch.  Allocates nothing.
+static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, hipStream_t stream,
+                        const frame_plan &f, const frame_memory &mem) {
+    const uint32_t spp = pr->sample_end - pr->sample_begin;
     // counters[0] = rays traced, counters[1] = next tile of the frame; [2], [3]: the same for the costing pass
-    HIP_TRY(hipMemsetAsync(scene->counter.p, 0, kCounters * sizeof(unsigned long long), stream));
-    if (stats) {
-        HIP_TRY(hipEventCreate(&ev.a));
-        HIP_TRY(hipEventCreate(&ev.b));
-        HIP_TRY(hipEventRecord(ev.a, stream));
-    }
-    dim3 grid(blocks), block(64 * waves);
+    HIP_TRY(hipMemsetAsync(mem.counters, 0, kCounters * sizeof(unsigned long long), stream));
+    dim3 grid(f.blocks), block(64 * f.waves);
     DCamera cam = to_dcamera(camera);
 #define RT_LAUNCH(T, L, W, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
     hipLaunchKernelGGL((k_render<T, L, W, C, D>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,   \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
-                       scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, scene->spill.p, ORDER, COST, SHIFT)
+                       scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT)
 #define RT_LAUNCH_TREE(T, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                      \
     do {                                                                                                                  \
         if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \
@@ -1189,21 +1327,46 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         else RT_LAUNCH_TREE(T, C, false, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                                              \
     } while (0)
     const uint32_t *order = nullptr;
-    if (ordered) {
+    if (f.ordered) {
         const uint32_t cost_tiles_x = (pr->nx + 7) / 8, n_cost = cost_tiles_x * ((pr->ny + 7) / 8);
-        uint32_t *cost = scene->tiles.p, *sorted = scene->tiles.p + n_cost;
+        uint32_t *cost = mem.tiles, *sorted = mem.tiles + n_cost;
         uint32_t probe = std::min(4u, std::max(1u, spp / 64u));   // measured: 1 sample ranks noisily, more than 4 costs more than it saves
         if (const char *e = getenv("RTIOW_TILE_PROBE")) probe = std::min<uint32_t>(spp, (uint32_t)std::max(1, atoi(e)));
-        RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, scene->counter.p + 2, (const uint32_t *)nullptr, cost, 3u);
-        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, tiles_x, n_tiles, 3u - tile_shift, sorted);
+        RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, mem.counters + 2, (const uint32_t *)nullptr, cost, 3u);
+        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, f.tiles_x, f.n_tiles, 3u - f.tile_shift, sorted);
         order = sorted;
     }
-    if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr, tile_shift);
-    else RT_LAUNCH_SHAPE(double, false, pr->sample_end, accum_dev, scene->counter.p, order, (uint32_t *)nullptr, tile_shift);
+    if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
+    else RT_LAUNCH_SHAPE(double, false, pr->sample_end, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
 #undef RT_LAUNCH_SHAPE
 #undef RT_LAUNCH_TREE
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, void *stream_v,
+              rt_stats *stats) {
+    if (int rc = check_render_args("rt_render", scene, camera, pr, accum_dev)) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    struct event_pair {   // destroyed on every return
+        hipEvent_t a = nullptr, b = nullptr;
+        ~event_pair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    const frame_plan f = plan_frame(scene, pr);
+    if (f.ordered && scene->tiles_capacity < 2 * (size_t)f.n_tiles) {   // costs of the 8x8 tiles (at most n_tiles of them), then the order
+        if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
+        HIP_TRY(scene->tiles.alloc(2 * (size_t)f.n_tiles));
+        scene->tiles_capacity = 2 * (size_t)f.n_tiles;
+    }
+    if (stats) {
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventRecord(ev.a, stream));
+    }
+    const frame_memory mem = {scene->counter.p, scene->tiles.p, scene->tiles_capacity, scene->spill.p};
+    if (int rc = launch_frame(scene, camera, pr, accum_dev, stream, f, mem)) return rc;
     if (stats) {
         HIP_TRY(hipEventRecord(ev.b, stream));
         HIP_TRY(hipEventSynchronize(ev.b));
@@ -1246,7 +1409,7 @@ int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_par
 int rt_resolve(int device, const float *accum_dev, size_t npix, uint32_t spp, uint8_t *rgb8_dev, void *stream) {
     if (npix && (!accum_dev || !rgb8_dev)) return fail(RT_E_INVALID, "rt_resolve: null argument");
     if (npix == 0) return RT_OK;
-    HIP_TRY(hipSetDevice(device));
+    if (int rc = use_device(device, nullptr)) return rc;
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(npix * 3)), dim3(kBlock), 0, (hipStream_t)stream, accum_dev, npix * 3, spp, rgb8_dev);
     HIP_TRY(hipGetLastError());
     return RT_OK;

@@ -66,7 +66,8 @@ __global__ void k_check(unsigned long long base, unsigned long long n, unsigned 
     if (mode == 4) { const double k = ldexp(1.0, (int)(g.next() % 400) - 200); for (int a = 0; a < 3; ++a) d[a] *= k; }
     if (mode == 5) for (int a = 0; a < 3; ++a) d[a] = g.sym();                                   // anywhere
     r.o = mk(o[0], o[1], o[2]); r.d = mk(d[0], d[1], d[2]); r.time = 0;
-    const RayCtx c = make_ctx(r);
+    const FarSlack none = {0, 0, 0, 0, 0};
+    const RayCtx c = make_ctx(r, none);
     // interval: the tracer's (0.001, huge), or ending / starting at the box
     double tmin = 0.001, tmax = DBL_MAX, e0;
     (void)box_test(box, c, -DBL_MAX, DBL_MAX, e0);

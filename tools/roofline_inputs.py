@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turns the PMC passes of tools/pmc_profile.sh into the two files bench.py's `roofline` reads.
+
+usage: tools/roofline_inputs.py PMC_DIR OUT_DIR CONFIG_KEY TAG
+
+Sums every counter over the k_render dispatches of one frame (costing pass + main launch: what
+rt_stats.kernel_ms times) and writes OUT_DIR/valu.json and OUT_DIR/traffic.json.
+
+Units (checked against tools/microbench/valu_rates under the same counters): the SQ cycle
+counters tick once per 4 clocks; SQ_THREAD_CYCLES_VALU adds, per VALU instruction pass, the
+number of active lanes, so a full 64-lane single-pass instruction adds 64 = the lane-slots a SIMD
+offers in 4 clocks; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  FETCH_SIZE and WRITE_SIZE are in
+KiB, and on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so the read side is
+doubled.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+N_XCD, N_SIMD = 8, 1024
+
+
+def main():
+    pmc_dir, out_dir, config_key, tag = sys.argv[1:5]
+    tot, span = {}, {}
+    for f in sorted(glob.glob(os.path.join(pmc_dir, "*_counter_collection.csv"))):
+        for row in csv.DictReader(open(f)):
+            if "k_render" not in row["Kernel_Name"]:
+                continue
+            tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if row["Counter_Name"] == "SQ_THREAD_CYCLES_VALU":
+                span[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+    g = tot.get
+    need = ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]
+    missing = [k for k in need if g(k) is None]
+    if missing:
+        sys.exit(f"missing counters {missing} in {pmc_dir}")
+    clocks = g("GRBM_GUI_ACTIVE") / N_XCD                    # shader clocks the frame's kernels were resident
+    lanes = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
+    valu = {
+        "config_key": config_key, "source": f"{tag}/pmc1024 (tools/pmc_profile.sh --spp 1024; sums over the frame's k_render dispatches)",
+        "SQ_THREAD_CYCLES_VALU": g("SQ_THREAD_CYCLES_VALU"), "SQ_ACTIVE_INST_VALU": g("SQ_ACTIVE_INST_VALU"), "SQ_INSTS_VALU": g("SQ_INSTS_VALU"),
+        "SQ_WAVE_CYCLES": g("SQ_WAVE_CYCLES"), "SQ_WAVES": g("SQ_WAVES"), "GRBM_GUI_ACTIVE": g("GRBM_GUI_ACTIVE"),
+        "lanes_active": lanes,                                                     # of 64, per VALU instruction
+        "valu_busy": 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * clocks),           # share of SIMD clocks with a VALU instruction executing
+        "occupancy": 4.0 * g("SQ_WAVE_CYCLES") / (N_SIMD * clocks),                # mean resident waves per SIMD
+        "valu_insts_per_launch": g("SQ_INSTS_VALU"),
+        "pmc_kernel_ms": sum(span.values()),
+        "pmc_shader_clock_ghz": clocks / (sum(span.values()) / 1e3) / 1e9 if span else None,
+    }
+    f64 = [g("SQ_INSTS_VALU_ADD_F64"), g("SQ_INSTS_VALU_MUL_F64"), g("SQ_INSTS_VALU_FMA_F64"), g("SQ_INSTS_VALU_TRANS_F64")]
+    if None not in f64:
+        valu["f64_insts_per_launch"] = {"add": f64[0], "mul": f64[1], "fma": f64[2], "trans": f64[3]}
+        # wave-instructions x the mean lane count of all VALU instructions (the counters do not split lanes by class)
+        valu["f64_flops_per_launch"] = (f64[0] + f64[1] + 2 * f64[2] + f64[3]) * lanes
+    json.dump(valu, open(os.path.join(out_dir, "valu.json"), "w"), indent=1)
+    print(json.dumps(valu))
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        traffic = {"config_key": config_key, "source": f"{tag}/pmc1024", "FETCH_SIZE_KiB": g("FETCH_SIZE"), "WRITE_SIZE_KiB": g("WRITE_SIZE"),
+                   "hbm_bytes_per_launch": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024}
+        json.dump(traffic, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+        print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    main()
