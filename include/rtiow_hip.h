@@ -148,6 +148,21 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 
+/* rt_render for callers that cannot allocate.  It has no counterpart in the reference: it
+ * is for code under HIP graph capture, tight serving loops and harnesses that forbid
+ * hipMalloc.  Same arguments and same image as rt_render, bit for bit, without the
+ * statistics (no events are created, nothing is synchronised).  The frame's working memory
+ * -- the four frame counters, the tile costs and tile order, and the deep stack entries of
+ * trees too large for LDS -- lies in a 32 MiB array that is part of the library's device
+ * image (every GPU the library runs on holds it until the process ends), so the call makes
+ * no hipMalloc / hipFree.  Limits, reported as RT_E_UNSUPPORTED: frames of 32 or more samples
+ * per pixel may have at most 2^19 tiles of 4x4 pixels (about 8.3 M pixels: 3840x2160 fits),
+ * and the scene's stack spill at most 24 MiB (the 10^6-sphere tree needs 17 MiB).  All calls
+ * on one GPU share the array, whichever scene they render: calls that overlap in time on one
+ * GPU race, also with each other across streams; rt_render calls do not use it. */
+int rt_render_noalloc(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
+                      void *accum_dev, void *stream);
+
 /* Same as rt_render, into a host buffer that is zeroed first (allocates and frees device memory). */
 int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
                    void *accum_host, rt_stats *stats);

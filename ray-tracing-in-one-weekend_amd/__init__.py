@@ -73,7 +73,7 @@ class rt_scene_desc(ctypes.Structure):
 # every symbol include/rtiow_hip.h declares
 HIP_SYMBOLS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_trace_batch",
                "rt_aabb_hit_batch", "rt_texture_batch", "rt_scatter_batch", "rt_camera_batch", "rt_render",
-               "rt_render_host", "rt_resolve"]
+               "rt_render_noalloc", "rt_render_host", "rt_resolve"]
 
 _hip = None
 _host = None
@@ -121,6 +121,7 @@ def hip():
         lib.rt_scatter_batch.argtypes = [vp, vp, vp, vp, vp, u32, sz, vp, vp, vp, vp]
         lib.rt_camera_batch.argtypes = [ctypes.c_int, ctypes.POINTER(rt_camera), vp, vp, u32, sz, vp, vp]
         lib.rt_render.argtypes = [vp, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, vp, ctypes.POINTER(rt_stats)]
+        lib.rt_render_noalloc.argtypes = [vp, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, vp]
         lib.rt_render_host.argtypes = [vp, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, ctypes.POINTER(rt_stats)]
         lib.rt_resolve.argtypes = [ctypes.c_int, vp, sz, u32, vp, vp]
         lib.rt_scene_destroy.argtypes = [vp]
@@ -317,3 +318,8 @@ class World:
         """rt_render into DEVICE memory (an integer address), asynchronously on `stream`."""
         _check(hip().rt_render(self.scene, ctypes.byref(cam), ctypes.byref(params), ctypes.c_void_p(accum_ptr),
                                ctypes.c_void_p(stream or 0), ctypes.byref(stats) if stats is not None else None), "rt_render")
+
+    def render_device_noalloc(self, cam, params, accum_ptr, stream=None):
+        """rt_render_noalloc: the same frame out of the library's per-GPU scratch array, no allocation, no statistics."""
+        _check(hip().rt_render_noalloc(self.scene, ctypes.byref(cam), ctypes.byref(params), ctypes.c_void_p(accum_ptr),
+                                       ctypes.c_void_p(stream or 0)), "rt_render_noalloc")

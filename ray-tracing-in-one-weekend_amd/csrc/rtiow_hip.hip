@@ -20,6 +20,7 @@
 #include <future>
 #include <thread>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -427,6 +428,36 @@ int use_device(int device, int *chosen) {
     return RT_OK;
 }
 
+}  // namespace
+
+// The working memory of rt_render_noalloc: one array per GPU the library runs on, held until the
+// process ends.  In host code the name `scratch` is a stand-in, not a device address: the address on
+// each device is asked for once (scratch_on_device) and only that pointer is handed to kernels and
+// to hipMemsetAsync.
+constexpr size_t kScratchCounterBytes = 256;                   // the four frame counters
+constexpr size_t kScratchTiles = (size_t)1 << 20;              // tile costs + tile order: at most 2^20 entries together
+constexpr size_t kScratchBytes = (size_t)32 << 20;             // in all
+constexpr size_t kScratchSpillInts = (kScratchBytes - kScratchCounterBytes - kScratchTiles * sizeof(uint32_t)) / sizeof(int);
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];
+std::mutex g_scratch_mutex;
+
+// address of `scratch` on `device`, which must be the current device; looked up on the first call per device
+int scratch_on_device(int device, unsigned char **out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RT_E_UNSUPPORTED, "device %d: only devices 0..%d have a scratch area", device, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RT_E_DEVICE, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = static_cast<unsigned char *>(g_scratch_ptr[device]);
+    return RT_OK;
+}
 }  // namespace
 
 struct rt_scene {
@@ -1055,6 +1086,10 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         memcpy(perm.data() + 512, desc->perlin_perm_z, 256);
     }
 
+    {   // the address of rt_render_noalloc's working memory on this device, while set-up may still take its time
+        unsigned char *unused;
+        if (int rc = scratch_on_device(device, &unused)) return rc;
+    }
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
     if (e == hipSuccess) e = s->leaves.upload(fl.leaf_boxes.data(), fl.leaf_boxes.size());
@@ -1259,7 +1294,8 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
     return RT_OK;
 }
 
-// Where one frame keeps its working memory.
+// Where one frame keeps its working memory: the scene's own buffers (rt_render) or the
+// per-device scratch array (rt_render_noalloc).
 struct frame_memory {
     unsigned long long *counters;   // kCounters entries
     uint32_t *tiles;                // tile costs, then the tile order; null = none available
@@ -1390,6 +1426,26 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         stats->paths = (uint64_t)pr->nx * pr->ny * (pr->sample_end - pr->sample_begin);
     }
     return RT_OK;
+}
+
+int rt_render_noalloc(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, void *stream_v) {
+    if (int rc = check_render_args("rt_render_noalloc", scene, camera, pr, accum_dev)) return rc;
+#ifdef RT_LANE_STATS
+    return fail(RT_E_UNSUPPORTED, "rt_render_noalloc: not available in the lane-statistics build");
+#endif
+    HIP_TRY(hipSetDevice(scene->device));
+    unsigned char *base = nullptr;
+    if (int rc = scratch_on_device(scene->device, &base)) return rc;   // (looked up when the device's first scene was created)
+    const frame_plan f = plan_frame(scene, pr);
+    if (f.ordered && 2 * (size_t)f.n_tiles > kScratchTiles)
+        return fail(RT_E_UNSUPPORTED, "rt_render_noalloc: %u tiles of %ux%u pixels; the scratch area orders at most %zu (images up to about %zu pixels)",
+                    f.n_tiles, 1u << f.tile_shift, 1u << f.tile_shift, kScratchTiles / 2, kScratchTiles / 2 * 16);
+    if (scene->spill_ints > kScratchSpillInts)
+        return fail(RT_E_UNSUPPORTED, "rt_render_noalloc: the scene's tree needs %zu bytes of stack spill, the scratch area holds %zu",
+                    scene->spill_ints * sizeof(int), kScratchSpillInts * sizeof(int));
+    const frame_memory mem = {reinterpret_cast<unsigned long long *>(base), reinterpret_cast<uint32_t *>(base + kScratchCounterBytes), kScratchTiles,
+                              scene->spill_ints ? reinterpret_cast<int *>(base + kScratchCounterBytes + kScratchTiles * sizeof(uint32_t)) : nullptr};
+    return launch_frame(scene, camera, pr, accum_dev, (hipStream_t)stream_v, f, mem);
 }
 
 int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_host, rt_stats *stats) {
