@@ -191,12 +191,14 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r, const FarSlack &far) {
                         (smallest >= 0x1p-100f && all < HUGE_VALF ? 0x1p-100f : HUGE_VALF);
     // the spatial slack of the sphere test for this origin (see FarSlack), per axis in units of t
     float wx = widen, wy = widen, wz = widen;
+#ifndef RT_NO_FAR_SLACK
     if (far.k > 0) {
         const float dx = (float)r.o.x - far.cx, dy = (float)r.o.y - far.cy, dz = (float)r.o.z - far.cz;
         const float L = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f + 0x1p-20f) + far.h;
         const float slack = __builtin_fminf(far.k * L * L, 0x1p-23f * L) * (1.0f + 0x1p-20f);   // (NaN or infinite L: infinite)
         wx += slack * __builtin_fabsf(c.ixf); wy += slack * __builtin_fabsf(c.iyf); wz += slack * __builtin_fabsf(c.izf);
     }
+#endif
     c.cnx = cx - wx; c.cny = cy - wy; c.cnz = cz - wz;
     c.cfx = cx + wx; c.cfy = cy + wy; c.cfz = cz + wz;
     return c;

@@ -5,6 +5,6 @@
 ARGS=$1; shift
 for rep in $(seq 1 ${REPS:-4}); do
   for lib in "$@"; do
-    echo -n "$lib "; RTIOW_HIP_LIB=$PWD/$lib timeout -k 10 120 python -u bench.py $ARGS --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['mean_radiance'],6), round(d['roofline']['kernel_ms'],2), 'min', round(d['roofline']['kernel_ms_min'],2))"
+    echo -n "$lib "; RTIOW_HIP_LIB=$PWD/$lib timeout -k 10 120 python -u bench.py $ARGS --timed-only 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['mean_radiance'],6), round(d['roofline']['kernel_ms'],2), 'min', round(d['roofline']['kernel_ms_min'],2))"
   done
 done

@@ -1,20 +1,25 @@
 #!/bin/bash
 # Produces the profile artefacts of a round under gpurun_out/TAG (copy the summaries to profiles/):
-#   1. rocprofv3 --kernel-trace --stats of the default bench run (the judged configuration)
-#   2. every PMC pass of tools/pmc_profile.sh over that same configuration (1920x1080, 1024 spp)
-#   3. valu.json / traffic.json: what bench.py's `roofline` reads (lane-slots, busy, occupancy; HBM bytes)
+#   1. every PMC pass of tools/pmc_profile.sh over the judged configuration (1920x1080, 1024 spp)
+#   2. valu.json / traffic.json from those passes: what bench.py's `roofline` reads (lane-slots,
+#      busy, occupancy; HBM bytes); also placed in profiles/ of this checkout for step 3
+#   3. the default bench run, un-profiled, with its roofline filled from step 2 -> bench.json
+#   4. rocprofv3 --kernel-trace --stats of the same run without the extra configurations, so that
+#      the statistics of k_render<float, ...> hold the timed 1024-spp launches only
 # usage: tools/profile_round.sh TAG      (run from the repository root, on the GPU box)
 set -u
 TAG=$1
 R=$(pwd)
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT" -o trace -- python3 "$R/bench.py" --steps 3 --warmup 1 > "$R/$OUT/bench.log" 2>&1 || { echo "trace run failed"; tail -5 "$R/$OUT/bench.log"; exit 1; }
-grep '"metric"' "$R/$OUT/bench.log" > "$R/$OUT/bench.json"
-cd "$R" && tools/pmc_profile.sh "$OUT/pmc1024" --spp 1024 || exit 1
+tools/pmc_profile.sh "$OUT/pmc1024" --spp 1024 || exit 1
 python3 tools/pmc_summary.py "$OUT/pmc1024" > "$OUT/pmc1024_summary.txt"
-python3 tools/roofline_inputs.py "$OUT/pmc1024" "$OUT" "book1 1920x1080 samples [0,1024)" "$TAG" || exit 1
+python3 tools/roofline_inputs.py "$OUT/pmc1024" "$OUT" "book1 1920x1080 samples [0,1024)" "$TAG" > /dev/null || exit 1
+cp "$OUT/valu.json" "$OUT/traffic.json" profiles/
+timeout -k 10 600 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT" -o trace -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-extra > "$R/$OUT/trace_bench.log" 2>&1 || { echo "trace run failed"; tail -5 "$R/$OUT/trace_bench.log"; exit 1; }
+cd "$R"
 cut -c1-200 "$OUT/trace_kernel_stats.csv"
-cut -c1-600 "$OUT/bench.json"
+cut -c1-900 "$OUT/bench.json"
 cat "$OUT/pmc1024_summary.txt"

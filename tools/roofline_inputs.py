@@ -44,7 +44,9 @@ def main():
         "SQ_THREAD_CYCLES_VALU": g("SQ_THREAD_CYCLES_VALU"), "SQ_ACTIVE_INST_VALU": g("SQ_ACTIVE_INST_VALU"), "SQ_INSTS_VALU": g("SQ_INSTS_VALU"),
         "SQ_WAVE_CYCLES": g("SQ_WAVE_CYCLES"), "SQ_WAVES": g("SQ_WAVES"), "GRBM_GUI_ACTIVE": g("GRBM_GUI_ACTIVE"),
         "lanes_active": lanes,                                                     # of 64, per VALU instruction
-        "valu_busy": 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * clocks),           # share of SIMD clocks with a VALU instruction executing
+        # VALU instruction passes issued per SIMD per 4 clocks; simple 32-bit integer instructions complete two
+        # per 4 clocks when several waves offer them, so this can exceed 1 (microbenchmark: 1.55 for v_add_u32)
+        "valu_busy": 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * clocks),
         "occupancy": 4.0 * g("SQ_WAVE_CYCLES") / (N_SIMD * clocks),                # mean resident waves per SIMD
         "valu_insts_per_launch": g("SQ_INSTS_VALU"),
         "pmc_kernel_ms": sum(span.values()),
