@@ -227,12 +227,11 @@ def extra_configs(torch, rt, main_world, local_rank):
     for name, scene, nx, ny, spp, cam_spec in cases:
         if scene not in worlds:
             t0 = time.perf_counter()
-            path = scene_file(rt, scene)
-            t_gen = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            worlds[scene] = (rt.World(path, device=local_rank), {"recipe_s": t_gen, "build_upload_s": time.perf_counter() - t0})
-            if scene.startswith("stress:"):
-                os.unlink(path)
+            if scene.startswith("stress:"):      # generated in memory: scene API objects -> reference BVH build -> layout -> upload
+                w_new = rt.World(None, device=local_rank, generator=("stress", 1, int(scene.split(":")[1])))
+            else:
+                w_new = rt.World(scene_file(rt, scene), device=local_rank)
+            worlds[scene] = (w_new, {"generate_build_upload_s": time.perf_counter() - t0})
         w, setup = worlds[scene]
         cam = rt.camera(camera15(cam_spec, nx / ny))
         accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")

@@ -140,6 +140,7 @@ def host():
         lib.rth_last_error.restype = ctypes.c_char_p
         lib.rth_generate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p]
         lib.rth_world_load.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.rth_world_generate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.rth_world_tables.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.rth_world_free.argtypes = [ctypes.c_void_p]
         lib.rth_world_scene.argtypes = [ctypes.c_void_p]
@@ -246,10 +247,16 @@ def camera_batch(cam, st, tape, device=-1):
 class World:
     """A recipe's world, built through the host scene API and resident on one GPU."""
 
-    def __init__(self, recipe_path, device=-1):
+    def __init__(self, recipe_path, device=-1, generator=None):
+        """The world of a recipe file, or -- generator=(kind, seed, n) -- of a scene generator directly."""
         self._h = ctypes.c_void_p()
         self.device = device
-        if host().rth_world_load(recipe_path.encode(), device, ctypes.byref(self._h)):
+        if generator is not None:
+            kind, seed, n = generator
+            rc = host().rth_world_generate(kind.encode(), seed, n, device, ctypes.byref(self._h))
+        else:
+            rc = host().rth_world_load(recipe_path.encode(), device, ctypes.byref(self._h))
+        if rc:
             raise RtError(host().rth_last_error().decode())
         self.scene = host().rth_world_scene(self._h)
         self.recipe_ids = _recipe_ids(self._h)   # table primitive -> recipe primitive

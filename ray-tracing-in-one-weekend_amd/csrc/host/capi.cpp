@@ -50,6 +50,16 @@ struct rth_world {
     }
 };
 
+namespace {
+recipe generate(const char* kind, uint32_t seed, int n) {
+    std::string const k = kind ? kind : "";
+    if (k == "two_perlin") return recipe_two_perlin_spheres();
+    if (k == "book1") return recipe_random_spheres(seed, false, false);
+    if (k == "book2") return recipe_random_spheres(seed, true, true);
+    if (k == "stress") return recipe_stress(seed, n);
+    throw std::runtime_error("unknown scene kind '" + k + "'");
+}
+}  // namespace
 extern "C" {
 
 const char* rth_last_error(void) { return g_error.c_str(); }
@@ -57,15 +67,22 @@ const char* rth_last_error(void) { return g_error.c_str(); }
 // kind: "two_perlin", "book1" (static spheres, grey ground), "book2" (moving spheres,
 // chequer ground: main.cpp:61-99 as written), "stress" (n spheres)
 int rth_generate(const char* kind, uint32_t seed, int n, const char* path) {
+    return guarded([&] { generate(kind, seed, n).save(path); });
+}
+
+// The same as rth_generate + rth_world_load without the detour through a recipe file: the
+// generator's world is built through the scene API, flattened and uploaded to `device`.
+int rth_world_generate(const char* kind, uint32_t seed, int n, int device, rth_world** out) {
+    *out = nullptr;
     return guarded([&] {
-        std::string const k = kind ? kind : "";
-        recipe rc;
-        if (k == "two_perlin") rc = recipe_two_perlin_spheres();
-        else if (k == "book1") rc = recipe_random_spheres(seed, false, false);
-        else if (k == "book2") rc = recipe_random_spheres(seed, true, true);
-        else if (k == "stress") rc = recipe_stress(seed, n);
-        else throw std::runtime_error("unknown scene kind '" + k + "'");
-        rc.save(path);
+        auto w = std::make_unique<rth_world>();
+        recipe const rc = generate(kind, seed, n);
+        std::vector<material const*> by_prim;
+        w->world = rc.instantiate(w->mt, &by_prim);
+        w->scene = std::make_unique<device_scene>(*w->world, device);
+        w->desc = w->scene->tables().desc();
+        w->number_prims(w->scene->tables(), by_prim);
+        *out = w.release();
     });
 }
 

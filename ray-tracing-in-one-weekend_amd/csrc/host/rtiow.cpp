@@ -435,7 +435,8 @@ bvh_node::build_plan bvh_node::draw_axes(std::mt19937& mt, size_t n, double t0, 
 bvh_node::bvh_node(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double const t0, double const t1)
     : bvh_node(draw_axes(mt, objects.size(), t0, t1), objects, 0, 0) {}
 
-bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object const>> objects, size_t const index, int const depth) {
+bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object const>> objects, size_t const index, int const depth)
+    : n_objects(objects.size()) {
     int const axis = plan.axis[index];
     double const t0 = plan.t0, t1 = plan.t1;
     // The reference sorts the pointers with a comparator that asks both objects for their
@@ -505,6 +506,16 @@ std::optional<aabb> bvh_node::bounding_box(double, double) const { return box; }
 
 // Nodes are numbered in pre-order: a node, its whole left subtree, its right subtree.
 int32_t bvh_node::flatten_child(scene_flattener& out) const {
+    // room for the whole subtree at once: growing the tables of a 10^6-sphere world by doubling
+    // copies them several times over (a sphere brings one primitive, one material and at most a
+    // few textures; only the root of a large tree finds the capacity short)
+    if (n_objects >= 4096 && out.prims.capacity() < out.prims.size() + n_objects) {
+        out.nodes.reserve(out.nodes.size() + n_objects);
+        out.prims.reserve(out.prims.size() + n_objects);
+        out.material_of_prim.reserve(out.material_of_prim.size() + n_objects);
+        out.materials.reserve(out.materials.size() + n_objects);
+        out.textures.reserve(out.textures.size() + n_objects);
+    }
     int32_t const me = (int32_t)out.nodes.size();
     out.nodes.emplace_back();
     int32_t const l = left->flatten_child(out);

@@ -268,6 +268,7 @@ class bvh_node final : public object {
     object const* left = nullptr;
     object const* right = nullptr;
     std::optional<aabb> box;
+    size_t n_objects = 0;   // objects under this node
     // the axis of every node, drawn before the build (see rtiow.cpp)
     struct build_plan;
     static build_plan draw_axes(std::mt19937& mt, size_t n, double t0, double t1);

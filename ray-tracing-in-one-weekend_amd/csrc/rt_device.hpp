@@ -58,8 +58,10 @@ __host__ __device__ inline float plane_up(double v) {
 
 // Every primitive under a SAFE child stays inside the child's box (static spheres), so
 // the descent may be skipped once the box starts beyond the best hit.  A moving sphere
-// leaves the box the reference gives it (moving_sphere.cpp:58): subtrees holding one are
-// always visited, as the reference visits them.
+// leaves the box the reference gives it (moving_sphere.cpp:58), but not by more than the scene's
+// reach (DScene::reach_a, reach_b): the node test skips a box when, grown by the reach on its entry
+// side, it starts beyond the best hit.  (The flags are kept for the leaf steps, which test the box
+// of a leaf with a moving sphere up front.)
 enum : uint32_t { NF_SAFE0 = 1u, NF_SAFE1 = 2u };
 
 // leaf reference: bit 31 set; bits 0-25 leaf number; bit 26: the leaf's second sphere alone (trees over
@@ -120,6 +122,13 @@ struct DScene {
     uint32_t stack_depth;     // entries per lane
     uint32_t recheck_all;     // test switch: treat every postponed box test as failed (see world_closest_voted)
     FarSlack far;
+    // How far a moving sphere can be from the box the reference gives it (moving_sphere.cpp:51-60
+    // covers the start position only, and shutter times reach outside [time0, time1]: camera.cpp:41).
+    // Its centre at ray time t is c0 + s dc with s = (t - time0) / (time1 - time0); along axis k it is
+    // at most reach_a[k] |t| + reach_b[k] away from c0, which the box contains together with the
+    // radius around it: every point of the moved sphere lies within the box grown by that much per
+    // axis.  Rounded up; 0 in scenes without moving spheres.
+    float reach_a[3], reach_b[3];
 };
 
 struct DCamera {
@@ -155,6 +164,9 @@ struct RayCtx {
     // c = -o/d per axis, c lowered for the planes the ray meets first and raised for the others
     // (see node_test)
     float ixf, iyf, izf, cnx, cny, cnz, cfx, cfy, cfz;
+    // by how much, in t, a moving sphere's hit may come before the ray's entry into its box, per axis
+    // (the reach of the scene's moving spheres at this ray's time over the speed along the axis)
+    float rnx, rny, rnz;
 };
 
 // The conservative test computes t = fma(plane, i, c) in single precision.  Against the exact
@@ -170,7 +182,8 @@ __device__ __forceinline__ float below(double x) { const float f = (float)x; ret
 __device__ __forceinline__ float above(double x) { const float f = (float)x; return f + __builtin_fabsf(f) * 0x1p-22f; }
 
 
-__device__ __forceinline__ RayCtx make_ctx(const Ray &r, const FarSlack &far) {
+// `reach`: reach_a[3], reach_b[3] of the scene (null: no moving spheres).
+__device__ __forceinline__ RayCtx make_ctx(const Ray &r, const FarSlack &far, const float *reach = nullptr) {
     RayCtx c;
     c.o = r.o; c.d = r.d; c.time = r.time;
     c.ix = 1.0 / r.d.x; c.iy = 1.0 / r.d.y; c.iz = 1.0 / r.d.z;
@@ -189,18 +202,26 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r, const FarSlack &far) {
     const float all = __builtin_fabsf(c.ixf) + __builtin_fabsf(c.iyf) + __builtin_fabsf(c.izf);
     const float widen = kWidenK * (__builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz)) +
                         (smallest >= 0x1p-100f && all < HUGE_VALF ? 0x1p-100f : HUGE_VALF);
+    float rx = 0, ry = 0, rz = 0, reach_all = 0;
+    if (reach) {
+        const float at = __builtin_fabsf((float)r.time) * (1.0f + 0x1p-20f);
+        rx = __builtin_fmaf(reach[0], at, reach[3]); ry = __builtin_fmaf(reach[1], at, reach[4]); rz = __builtin_fmaf(reach[2], at, reach[5]);
+        reach_all = rx + ry + rz;
+    }
     // the spatial slack of the sphere test for this origin (see FarSlack), per axis in units of t
     float wx = widen, wy = widen, wz = widen;
 #ifndef RT_NO_FAR_SLACK
     if (far.k > 0) {
         const float dx = (float)r.o.x - far.cx, dy = (float)r.o.y - far.cy, dz = (float)r.o.z - far.cz;
-        const float L = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f + 0x1p-20f) + far.h;
+        const float L = __builtin_sqrtf(dx * dx + dy * dy + dz * dz) * (1.0f + 0x1p-20f) + far.h + reach_all;
         const float slack = __builtin_fminf(far.k * L * L, 0x1p-23f * L) * (1.0f + 0x1p-20f);   // (NaN or infinite L: infinite)
         wx += slack * __builtin_fabsf(c.ixf); wy += slack * __builtin_fabsf(c.iyf); wz += slack * __builtin_fabsf(c.izf);
     }
 #endif
-    c.cnx = cx - wx; c.cny = cy - wy; c.cnz = cz - wz;
     c.cfx = cx + wx; c.cfy = cy + wy; c.cfz = cz + wz;
+    c.cnx = cx - wx; c.cny = cy - wy; c.cnz = cz - wz;
+    // (0 * inf gives NaN, which drops out of the skip test's maximum: no constraint from that axis)
+    c.rnx = rx * __builtin_fabsf(c.ixf) * (1.0f + 0x1p-20f); c.rny = ry * __builtin_fabsf(c.iyf) * (1.0f + 0x1p-20f); c.rnz = rz * __builtin_fabsf(c.izf) * (1.0f + 0x1p-20f);
     return c;
 }
 
@@ -441,8 +462,12 @@ __device__ __forceinline__ void node_decide(int32_t c0, int32_t c1, bool h0, boo
 // constants carry the rounding error bound in advance (see make_ctx), a NaN slab value (0 * inf)
 // drops out of max3/min3 as it leaves the reference's bounds unchanged, and NaN bounds pass.
 // `entry` is a lower bound of the exact entry distance.
-// `limit` is a second upper bound (the best hit so far, for children that may be skipped behind it;
-// +inf for none): it rides along in the three-operand minimum for free.
+// `limit` is the best hit so far rounded up (+inf for none).  A box that starts beyond it is skipped.
+// STILL (every sphere stays in its box): the limit rides along in the three-operand minimum for free.
+// Otherwise the spheres of the box may be up to the scene's reach outside it, and the box is skipped
+// when the box grown by the reach on its entry side starts beyond the limit (the hit point of a
+// moved sphere lies inside the grown box, hence behind that entry).
+template <bool STILL>
 __device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy, float nz, float fz, const RayCtx &r,
                                           float tmin_below, float tmax_above, float limit, float &entry) {
     const float tnx = __builtin_fmaf(nx, r.ixf, r.cnx), tfx = __builtin_fmaf(fx, r.ixf, r.cfx);
@@ -455,19 +480,24 @@ __device__ __forceinline__ bool node_test(float nx, float fx, float ny, float fy
     // first re-canonicalise the two interval bounds in every step, against signalling NaNs that
     // nothing here produces
     float x_in, e_in;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above), "v"(limit));
+    if (STILL) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above), "v"(limit));
+    else asm("v_min_f32 %0, %1, %2" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above));
     asm("v_max_f32 %0, %1, %2" : "=v"(e_in) : "v"(e_lo), "v"(tmin_below));
-    return !(x_in < e_in);
+    bool hit = !(x_in < e_in);
+    if (!STILL) {
+        float e_grown;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(e_grown) : "v"(tnx - r.rnx), "v"(tny - r.rny), "v"(tnz - r.rnz));
+        hit = hit && !(limit < e_grown);
+    }
+    return hit;
 }
 
 // One node read from device memory: test both child boxes, continue with the nearer, push the
-// farther.  A SAFE child is also skipped when it starts beyond the best hit so far (tv.bt_above, +inf
-// while there is none).
-// ALL_SAFE: every child may (the scene has no moving sphere), so the flags are not looked at.
-template <bool SPILL, bool ALL_SAFE = false>
+// farther.  A child is also skipped when it starts beyond the best hit so far (tv.bt_above, +inf
+// while there is none); see node_test.  STILL: the scene has no moving sphere.
+template <bool SPILL, bool STILL = false>
 __device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
     const DNode *nd = nodes + tv.cur;
-    const uint32_t flags = ALL_SAFE ? 0u : nd->flags;
     const int32_t c0 = nd->child[0], c1 = nd->child[1];
     float b[2][6];
 #pragma unroll
@@ -476,9 +506,8 @@ __device__ __forceinline__ void node_step(const DNode *nodes, const RayCtx &r, f
     bool h[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const float limit = ALL_SAFE || (flags & (c ? NF_SAFE1 : NF_SAFE0)) ? tv.bt_above : HUGE_VALF;
-        h[c] = node_test(r.nx8 ? b[c][1] : b[c][0], r.nx8 ? b[c][0] : b[c][1], r.ny8 ? b[c][3] : b[c][2], r.ny8 ? b[c][2] : b[c][3],
-                         r.nz8 ? b[c][5] : b[c][4], r.nz8 ? b[c][4] : b[c][5], r, tmin_below, tmax_above, limit, e[c]);
+        h[c] = node_test<STILL>(r.nx8 ? b[c][1] : b[c][0], r.nx8 ? b[c][0] : b[c][1], r.ny8 ? b[c][3] : b[c][2], r.ny8 ? b[c][2] : b[c][3],
+                         r.nz8 ? b[c][5] : b[c][4], r.nz8 ? b[c][4] : b[c][5], r, tmin_below, tmax_above, tv.bt_above, e[c]);
     }
     node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
 }
@@ -532,12 +561,11 @@ __device__ __forceinline__ PlaneAddr plane_addresses(const char *lnodes, const R
 
 // node_step on the LDS copy.  PREMUL: node references are byte offsets of the records already
 // (trees that live in LDS whole), not indices.
-template <bool SPILL, bool PREMUL, bool ALL_SAFE>
+template <bool SPILL, bool PREMUL, bool STILL>
 __device__ __forceinline__ void node_step_lds(const char *lnodes, const PlaneAddr &pa, const RayCtx &r, float tmin_below, float tmax_above, const LaneStack &st, Trav &tv) {
     const uint32_t off = PREMUL ? (uint32_t)tv.cur : (uint32_t)tv.cur * LNODE_STRIDE;
     const char *nd = lnodes + off;
     const int32_t c0 = *reinterpret_cast<const int32_t *>(nd + 48), c1 = *reinterpret_cast<const int32_t *>(nd + 52);
-    const uint32_t flags = ALL_SAFE ? 0u : *reinterpret_cast<const uint32_t *>(nd + 56);
     float e[2];
     bool h[2];
     float pl[2][6];   // all twelve planes first
@@ -549,8 +577,7 @@ __device__ __forceinline__ void node_step_lds(const char *lnodes, const PlaneAdd
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const float limit = ALL_SAFE || (flags & (c ? NF_SAFE1 : NF_SAFE0)) ? tv.bt_above : HUGE_VALF;
-        h[c] = node_test(pl[c][0], pl[c][1], pl[c][2], pl[c][3], pl[c][4], pl[c][5], r, tmin_below, tmax_above, limit, e[c]);
+        h[c] = node_test<STILL>(pl[c][0], pl[c][1], pl[c][2], pl[c][3], pl[c][4], pl[c][5], r, tmin_below, tmax_above, tv.bt_above, e[c]);
     }
     node_decide<SPILL>(c0, c1, h[0], h[1], e[0], e[1], st, tv);
 }

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_batch(DScene sc, const rt_ray 
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Ray r = load_ray(rays + i);
-    RayCtx ctx = make_ctx(r, sc.far);
+    RayCtx ctx = make_ctx(r, sc.far, sc.reach_a);
     double t;
     int prim;
     rt_hit h;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // entries spill to it.
 constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
 constexpr size_t kCameraLds = 192;            // the block's copy of the camera
-constexpr size_t kHeadLds = kCameraLds + 32;  // ... followed by the scene's FarSlack
+constexpr size_t kHeadLds = kCameraLds + 48;  // ... followed by the scene's FarSlack and reach
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 #ifdef RT_LANE_STATS
 constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics slots per wave of up to 1024 blocks
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
     static_assert(sizeof(DCamera) == kCameraLds, "camera copy in LDS");
     if (tid < kCameraLds / sizeof(double)) reinterpret_cast<double *>(lds_raw)[tid] = reinterpret_cast<const double *>(&cam_arg)[tid];
     static_assert(sizeof(FarSlack) == 20 && kHeadLds - kCameraLds >= sizeof(FarSlack), "far slack copy in LDS");
-    if (tid < sizeof(FarSlack) / sizeof(float)) reinterpret_cast<float *>(lds_raw + kCameraLds)[tid] = reinterpret_cast<const float *>(&sc.far)[tid];
+    static_assert(offsetof(DScene, reach_a) == offsetof(DScene, far) + 20 && offsetof(DScene, reach_b) == offsetof(DScene, far) + 32 && kHeadLds - kCameraLds >= 44,
+                  "far slack and reach are copied together");
+    if (tid < 11) reinterpret_cast<float *>(lds_raw + kCameraLds)[tid] = reinterpret_cast<const float *>(&sc.far)[tid];
     double *tile_sum = reinterpret_cast<double *>(lds_raw + kHeadLds) + wave * 192;
     char *const stacks = lds_raw + kHeadLds + kRenderWaves * 192 * sizeof(double);
     char *ltree = stacks + (size_t)stack_cap * kRenderBlock * sizeof(int);
@@ -285,7 +288,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
             lane_stats.add(2, (uint32_t)__popcll(__ballot(alive)));
             if (want != 0) lane_stats.add(5, (uint32_t)__popcll(want));
             if (alive) {
-                const RayCtx ctx = make_ctx(r, *reinterpret_cast<const FarSlack *>(lds_raw + kCameraLds));
+                const float *head = reinterpret_cast<const float *>(lds_raw + kCameraLds);
+                const RayCtx ctx = make_ctx(r, *reinterpret_cast<const FarSlack *>(head), DEFER ? nullptr : head + 5);
                 double t;
                 int prim;
                 ++nrays;
@@ -478,6 +482,9 @@ struct rt_scene {
     size_t spill_ints = 0;
     dev_buf<uint32_t> tiles;                 // per tile: measured cost, then the render order
     size_t tiles_capacity = 0;
+    // the frame whose tile order `tiles` holds: a frame of the same view and size reuses it
+    struct order_key { rt_camera camera; uint32_t nx, ny, max_depth, tile_shift; double t_min; } order_of{};
+    bool order_valid = false;
     size_t lds_bytes = 0;                    // stacks of the batch kernels
     // shape of the render kernel for this scene (see k_render)
     bool render_lds_tree = false;
@@ -1131,6 +1138,21 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         s->render_defer = static_scene;
         s->d.recheck_all = getenv("RTIOW_RECHECK_ALL_LEAVES") ? 1u : 0u;
     }
+    {   // the reach of the moving spheres, per axis: |c(t) - c0| <= |dc| |t - time0| / |time1 - time0| <= reach_a |t| + reach_b
+        auto up = [](double v) { const float f = (float)v; return (double)f < v ? nextafterf(f, HUGE_VALF) : f; };
+        for (int k = 0; k < 3; ++k) {
+            double a = 0, b = 0;
+            for (const DPrim &p : fl.prims) {
+                if (p.orig < 0 || p.kind == PK_STATIC) continue;
+                const double len = std::fabs(p.dc[k]), span = std::fabs(p.t1 - p.t0);
+                const double pa = len / span, pb = len * std::fabs(p.t0) / span;   // (a zero span: infinite or NaN)
+                a = (pa >= a) ? pa : (std::isnan(pa) ? HUGE_VAL : a);
+                b = (pb >= b) ? pb : (std::isnan(pb) ? HUGE_VAL : b);
+            }
+            s->d.reach_a[k] = up(a * (1 + 0x1p-20));
+            s->d.reach_b[k] = up(b * (1 + 0x1p-20));
+        }
+    }
     bool any_static = false;
     for (const DPrim &p : fl.prims) any_static = any_static || (p.orig >= 0 && p.kind == PK_STATIC);
     if (any_static) {   // see FarSlack
@@ -1341,7 +1363,7 @@ static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) 
 // Queues one frame on `stream`: counters cleared, costing pass and tile sort when the plan says so,
 // then the main launch.  Allocates nothing.
 static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, hipStream_t stream,
-                        const frame_plan &f, const frame_memory &mem) {
+                        const frame_plan &f, const frame_memory &mem, bool order_on_file) {
     const uint32_t spp = pr->sample_end - pr->sample_begin;
     // counters[0] = rays traced, counters[1] = next tile of the frame; [2], [3]: the same for the costing pass
     HIP_TRY(hipMemsetAsync(mem.counters, 0, kCounters * sizeof(unsigned long long), stream));
@@ -1368,8 +1390,10 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
         uint32_t *cost = mem.tiles, *sorted = mem.tiles + n_cost;
         uint32_t probe = std::min(4u, std::max(1u, spp / 64u));   // measured: 1 sample ranks noisily, more than 4 costs more than it saves
         if (const char *e = getenv("RTIOW_TILE_PROBE")) probe = std::min<uint32_t>(spp, (uint32_t)std::max(1, atoi(e)));
-        RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, mem.counters + 2, (const uint32_t *)nullptr, cost, 3u);
-        hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, f.tiles_x, f.n_tiles, 3u - f.tile_shift, sorted);
+        if (!order_on_file) {
+            RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, mem.counters + 2, (const uint32_t *)nullptr, cost, 3u);
+            hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, f.tiles_x, f.n_tiles, 3u - f.tile_shift, sorted);
+        }
         order = sorted;
     }
     if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
@@ -1393,6 +1417,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     const frame_plan f = plan_frame(scene, pr);
     if (f.ordered && scene->tiles_capacity < 2 * (size_t)f.n_tiles) {   // costs of the 8x8 tiles (at most n_tiles of them), then the order
         if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
+        scene->order_valid = false;
         HIP_TRY(scene->tiles.alloc(2 * (size_t)f.n_tiles));
         scene->tiles_capacity = 2 * (size_t)f.n_tiles;
     }
@@ -1401,8 +1426,21 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, stream));
     }
+    // A tile's cost is a property of the view, not of the samples: a frame of the same camera, size
+    // and depth limit as the last ordered frame of this scene (the next frame of an animation's
+    // still shot, the next batch of samples of a progressive render, the next step of a benchmark)
+    // takes over its order and skips the costing pass.  RTIOW_TILE_COST_REUSE=0 measures every frame.
+    bool order_on_file = false;
+    if (f.ordered) {
+        rt_scene::order_key key{};
+        key.camera = *camera; key.nx = pr->nx; key.ny = pr->ny; key.max_depth = pr->max_depth; key.tile_shift = f.tile_shift; key.t_min = pr->t_min;
+        const char *reuse = getenv("RTIOW_TILE_COST_REUSE");
+        order_on_file = scene->order_valid && memcmp(&key, &scene->order_of, sizeof key) == 0 && !(reuse && atoi(reuse) == 0) && !getenv("RTIOW_TILE_PROBE");
+        scene->order_of = key;
+        scene->order_valid = true;
+    }
     const frame_memory mem = {scene->counter.p, scene->tiles.p, scene->tiles_capacity, scene->spill.p};
-    if (int rc = launch_frame(scene, camera, pr, accum_dev, stream, f, mem)) return rc;
+    if (int rc = launch_frame(scene, camera, pr, accum_dev, stream, f, mem, order_on_file)) { scene->order_valid = false; return rc; }
     if (stats) {
         HIP_TRY(hipEventRecord(ev.b, stream));
         HIP_TRY(hipEventSynchronize(ev.b));
@@ -1445,7 +1483,7 @@ int rt_render_noalloc(rt_scene *scene, const rt_camera *camera, const rt_render_
                     scene->spill_ints * sizeof(int), kScratchSpillInts * sizeof(int));
     const frame_memory mem = {reinterpret_cast<unsigned long long *>(base), reinterpret_cast<uint32_t *>(base + kScratchCounterBytes), kScratchTiles,
                               scene->spill_ints ? reinterpret_cast<int *>(base + kScratchCounterBytes + kScratchTiles * sizeof(uint32_t)) : nullptr};
-    return launch_frame(scene, camera, pr, accum_dev, (hipStream_t)stream_v, f, mem);
+    return launch_frame(scene, camera, pr, accum_dev, (hipStream_t)stream_v, f, mem, false);   // (the array is shared: every frame is costed)
 }
 
 int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_host, rt_stats *stats) {

@@ -81,7 +81,7 @@ __global__ void k_check(unsigned long long base, unsigned long long n, unsigned 
     float bx[6];
     for (int k = 0; k < 6; ++k) bx[k] = (k & 1) ? plane_up(box[k]) : plane_down(box[k]);
     float e32;
-    const bool cons = node_test(c.nx8 ? bx[1] : bx[0], c.nx8 ? bx[0] : bx[1], c.ny8 ? bx[3] : bx[2], c.ny8 ? bx[2] : bx[3],
+    const bool cons = node_test<true>(c.nx8 ? bx[1] : bx[0], c.nx8 ? bx[0] : bx[1], c.ny8 ? bx[3] : bx[2], c.ny8 ? bx[2] : bx[3],
                                 c.nz8 ? bx[5] : bx[4], c.nz8 ? bx[4] : bx[5], c, below(tmin), above(tmax), HUGE_VALF, e32);
     atomicAdd(counts + 0, 1ull);
     if (exact) atomicAdd(counts + 1, 1ull);
