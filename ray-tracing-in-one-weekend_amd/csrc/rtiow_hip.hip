@@ -485,6 +485,9 @@ struct rt_scene {
     // the frame whose tile order `tiles` holds: a frame of the same view and size reuses it
     struct order_key { rt_camera camera; uint32_t nx, ny, max_depth, tile_shift; double t_min; } order_of{};
     bool order_valid = false;
+    // static scenes whose sphere boxes carry the far slack: frames whose camera lies within
+    // far_free_radius of far_free_centre render without the per-segment slack (0: never)
+    double far_free_centre[3] = {0, 0, 0}, far_free_radius = 0;
     size_t lds_bytes = 0;                    // stacks of the batch kernels
     // shape of the render kernel for this scene (see k_render)
     bool render_lds_tree = false;
@@ -861,11 +864,21 @@ struct flattener {
         // the radius, 2^-20 of it, and 2^-30 of the largest coordinate (a radius of zero, or one far
         // below the centre's magnitude, still gets a box wider than the test's rounding)
         const double far = std::fmax(std::fmax(std::fabs(p.c0[0]), std::fabs(p.c0[1])), std::fabs(p.c0[2]));
-        const double r = std::fabs(p.r) * (1.0 + 0x1p-20) + 0x1p-30 * (far + std::fabs(p.r));
+        // ... and, when the scene allows it (far_allowance > 0), what the rounding of the reference's
+        // discriminant can add for a ray that starts up to far_allowance from the centre (see FarSlack)
+        const double r = std::fabs(p.r) * (1.0 + 0x1p-20) + 0x1p-30 * (far + std::fabs(p.r)) + far_pad(std::fabs(p.r));
         for (int a = 0; a < 3; ++a) { b[2 * a] = p.c0[a] - r; b[2 * a + 1] = p.c0[a] + r; }
     }
 
     bool static_scene = false;   // no moving sphere: the tree is built over single spheres
+
+    // Static scenes: the largest distance between a ray's origin and a sphere's centre that the
+    // padding of the spheres' own boxes covers (0: none is built in, every segment computes its slack).
+    double far_allowance = 0;
+    double far_pad(double radius) const {
+        if (!(far_allowance > 0)) return 0;
+        return std::fmin(0x1p-49 * far_allowance * far_allowance / radius, 0x1p-23 * far_allowance) * (1 + 0x1p-10);
+    }
 
     // the whole bvh item rooted at description node `id`, re-clustered
     int32_t build_clustered(int32_t id, bool &safe) {
@@ -987,6 +1000,31 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     fl.static_scene = !(static_env && atoi(static_env) == 0);
     for (uint32_t i = 0; i < desc->n_prims; ++i)
         if (desc->prims[i].kind == RT_PRIM_MOVING_SPHERE) fl.static_scene = false;
+    // The world's extent (centre and half-diagonal of the box around all spheres).  In a scene of
+    // static spheres every ray starts on a sphere or at the camera: with the camera within three
+    // half-diagonals of the centre no origin is farther than four from any sphere's centre, and when
+    // the slack of the sphere test at that distance is a small part of every radius it is built
+    // into the spheres' boxes, so that such frames need no per-segment slack (rt_render checks the
+    // camera; rays from anywhere else -- rt_trace_batch -- always compute theirs).
+    double extent_c[3] = {0, 0, 0}, extent_h = 0;
+    if (fl.static_scene && desc->n_prims) {
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (uint32_t i = 0; i < desc->n_prims; ++i)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::fmin(lo[a], desc->prims[i].centre0[a] - std::fabs(desc->prims[i].radius));
+                hi[a] = std::fmax(hi[a], desc->prims[i].centre0[a] + std::fabs(desc->prims[i].radius));
+            }
+        double h2 = 0;
+        for (int a = 0; a < 3; ++a) { extent_c[a] = 0.5 * (lo[a] + hi[a]); const double e = 0.5 * (hi[a] - lo[a]); h2 += e * e; }
+        extent_h = std::sqrt(h2) * (1 + 0x1p-30);
+        bool small = std::isfinite(extent_h) && extent_h > 0 && !getenv("RTIOW_FAR_SLACK_ALWAYS");
+        fl.far_allowance = 4 * extent_h;
+        for (uint32_t i = 0; i < desc->n_prims && small; ++i) {
+            const double r = std::fabs(desc->prims[i].radius);
+            small = r > 0 && fl.far_pad(r) <= 0x1p-10 * r;
+        }
+        if (!small) fl.far_allowance = 0;
+    }
     std::vector<DItem> items;
     for (uint32_t i = 0; i < desc->n_items; ++i) {
         const rt_item_desc &it = desc->items[i];
@@ -1152,6 +1190,10 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             s->d.reach_a[k] = up(a * (1 + 0x1p-20));
             s->d.reach_b[k] = up(b * (1 + 0x1p-20));
         }
+    }
+    if (static_scene && fl.far_allowance > 0) {
+        for (int a = 0; a < 3; ++a) s->far_free_centre[a] = extent_c[a];
+        s->far_free_radius = 3 * extent_h * (1 - 0x1p-20);
     }
     bool any_static = false;
     for (const DPrim &p : fl.prims) any_static = any_static || (p.orig >= 0 && p.kind == PK_STATIC);
@@ -1369,8 +1411,14 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     HIP_TRY(hipMemsetAsync(mem.counters, 0, kCounters * sizeof(unsigned long long), stream));
     dim3 grid(f.blocks), block(64 * f.waves);
     DCamera cam = to_dcamera(camera);
+    DScene dsc = scene->d;
+    if (scene->far_free_radius > 0) {   // the sphere boxes' padding covers every origin of this frame: no per-segment slack
+        double d2 = 0;
+        for (int a = 0; a < 3; ++a) { const double e = camera->origin[a] - scene->far_free_centre[a]; d2 += e * e; }
+        if (std::sqrt(d2) + std::fabs(camera->lens_radius) * 2 <= scene->far_free_radius) dsc.far.k = 0;
+    }
 #define RT_LAUNCH(T, L, W, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
-    hipLaunchKernelGGL((k_render<T, L, W, C, D>), grid, block, scene->render_lds_bytes, stream, scene->d, cam, pr->nx, pr->ny,   \
+    hipLaunchKernelGGL((k_render<T, L, W, C, D>), grid, block, scene->render_lds_bytes, stream, dsc, cam, pr->nx, pr->ny,   \
                        pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
                        scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT)
 #define RT_LAUNCH_TREE(T, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                      \

@@ -604,6 +604,22 @@ def test_edge_frames_match_oracle(rt, orc, worlds, nx, ny, s0, s1, depth, apertu
         assert not got.any()
 
 
+@pytest.mark.parametrize("scene,distance", [("book1", 1e5), ("book1", 3e7), ("book2", 1e6), ("stress4096", 1e6)])
+def test_frames_from_far_away_match_oracle(rt, orc, worlds, scene, distance):
+    # A camera far outside the scene: the rounding of the reference's sphere test then reaches a
+    # sizeable part of the small spheres' radii (2^-50 L^2 / r), beyond the padding of the boxes the
+    # static scenes give each sphere, and every segment has to widen the boxes it tests by that slack.
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[0:3] = np.array([13.0, 4.0, 3.0]) * (distance / 13.9)
+    cam15[9] = np.degrees(2 * np.arctan(6.0 / distance))      # the scene's middle fills the frame
+    cam15[12] = distance
+    got, stats = worlds(scene).render(rt.camera(cam15), 96, 48, 0, 3, 17, rt.RT_ACCUM_F64)
+    exp, counters = orc.Scene(recipe(scene)).render(cam15, 96, 48, 0, 3, 17, orc.ORC_RNG_STREAM)
+    assert stats.rays == counters.rays
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+    assert stats.rays > 1.5 * stats.paths                       # the rays do meet the scene
+
+
 def test_empty_world_is_all_sky(rt, orc, tmp_path):
     # object_list::hit over no objects never hits (object_list.cpp:12-26): every path is one sky ray
     path = tmp_path / "empty.recipe"
