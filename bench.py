@@ -231,7 +231,7 @@ def extra_configs(torch, rt, main_world, local_rank):
                 w_new = rt.World(None, device=local_rank, generator=("stress", 1, int(scene.split(":")[1])))
             else:
                 w_new = rt.World(scene_file(rt, scene), device=local_rank)
-            worlds[scene] = (w_new, {"generate_build_upload_s": time.perf_counter() - t0})
+            worlds[scene] = (w_new, dict(w_new.setup_seconds(), total_s=time.perf_counter() - t0))
         w, setup = worlds[scene]
         cam = rt.camera(camera15(cam_spec, nx / ny))
         accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")
@@ -301,11 +301,14 @@ def main():
             dist.init_process_group(args.backend)
 
     rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
-    scene_path = scene_file(rt, scene)
     cam15 = camera15(cfg["camera"], nx / ny)
     t_build = time.perf_counter()
-    w = rt.World(scene_path, device=local_rank)
+    if scene.startswith("stress:"):      # generated in memory: scene API objects -> reference BVH build -> layout -> upload
+        w = rt.World(None, device=local_rank, generator=("stress", 1, int(scene.split(":")[1])))
+    else:
+        w = rt.World(scene_file(rt, scene), device=local_rank)
     t_build = time.perf_counter() - t_build
+    scene_path = scene_file(rt, scene) if rank == 0 else None   # (the oracle and the reference renderer read the recipe)
     cam = rt.camera(cam15)
 
     accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")
@@ -395,7 +398,7 @@ def main():
                                    + ", max depth 50, BVH built by the reference algorithm)",
                        "nx": nx, "ny": ny, "spp_per_gpu": my_spp, "spp_per_frame": frame_spp,
                        "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
-            "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build,
+            "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build, "scene_setup": w.setup_seconds(),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -406,7 +409,7 @@ def main():
             line["extra_configs"] = extra_configs(torch, rt, w, local_rank)
         print(json.dumps(line), flush=True)
     w.close()
-    if scene.startswith("stress:"):
+    if scene.startswith("stress:") and scene_path:
         os.unlink(scene_path)
     if world > 1:
         dist.destroy_process_group()

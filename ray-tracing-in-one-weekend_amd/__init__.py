@@ -147,6 +147,7 @@ def host():
         lib.rth_world_scene.restype = ctypes.c_void_p
         lib.rth_world_desc.argtypes = [ctypes.c_void_p]
         lib.rth_world_desc.restype = ctypes.POINTER(rt_scene_desc)
+        lib.rth_world_seconds.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         lib.rth_world_recipe_ids.argtypes = [ctypes.c_void_p]
         lib.rth_world_recipe_ids.restype = ctypes.POINTER(ctypes.c_int32)
         lib.rth_camera.argtypes = [ctypes.c_void_p, ctypes.POINTER(rt_camera)]
@@ -194,7 +195,12 @@ def perlin_tables():
 
 def _recipe_ids(h):
     n = host().rth_world_desc(h).contents.n_prims
-    return np.ctypeslib.as_array(host().rth_world_recipe_ids(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    if not n:
+        return np.zeros(0, np.int32)
+    p = host().rth_world_recipe_ids(h)
+    if not p:
+        raise RtError(host().rth_last_error().decode())
+    return np.ctypeslib.as_array(p, shape=(n,)).copy()
 
 
 def _tables(desc, ids):
@@ -259,8 +265,27 @@ class World:
         if rc:
             raise RtError(host().rth_last_error().decode())
         self.scene = host().rth_world_scene(self._h)
-        self.recipe_ids = _recipe_ids(self._h)   # table primitive -> recipe primitive
-        self.table_ids = np.argsort(self.recipe_ids).astype(np.int32)
+        self._recipe_ids = self._table_ids = None
+
+    @property
+    def recipe_ids(self):
+        """table primitive -> recipe primitive (worked out on first use: a million-sphere world that is only rendered never asks)"""
+        if self._recipe_ids is None:
+            self._recipe_ids = _recipe_ids(self._h)
+        return self._recipe_ids
+
+    @property
+    def table_ids(self):
+        if self._table_ids is None:
+            self._table_ids = np.argsort(self.recipe_ids).astype(np.int32)
+        return self._table_ids
+
+    def setup_seconds(self):
+        """Seconds spent making the recipe (generator or file), in the scene API (objects + bvh_node build),
+        flattening, and in rt_scene_create (layout + upload)."""
+        out = (ctypes.c_double * 4)()
+        host().rth_world_seconds(self._h, out)
+        return {"recipe_s": out[0], "objects_and_bvh_build_s": out[1], "flatten_s": out[2], "scene_create_s": out[3]}
 
     def close(self):
         if self._h:

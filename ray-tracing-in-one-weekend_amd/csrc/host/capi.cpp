@@ -2,10 +2,12 @@
 // C++ classes directly (the Python harness in tests/ and bench.py).  They only build
 // worlds, cameras and recipes; every per-ray call goes to rtiow_hip.h with the
 // rt_scene handle obtained here.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
-#include <map>
 #include <vector>
 #include <memory>
 #include <stdexcept>
@@ -40,13 +42,51 @@ struct rth_world {
     std::unique_ptr<device_scene> scene;
     std::unique_ptr<scene_flattener> flat;   // tables of a world that was not uploaded
     rt_scene_desc desc{};
-    std::vector<int32_t> recipe_id;           // recipe primitive number of each table primitive
+    std::vector<int32_t> recipe_id;           // recipe primitive number of each table primitive (filled on demand)
+    std::vector<material const*> by_prim;     // the recipe's primitives' materials, in recipe order
+    double seconds[4] = {0, 0, 0, 0};         // generate or load | objects + bvh_node build | flatten | rt_scene_create
 
-    void number_prims(scene_flattener const& tables, std::vector<material const*> const& by_prim) {
-        std::map<material const*, int32_t> id;
-        for (size_t i = 0; i < by_prim.size(); ++i) id[by_prim[i]] = (int32_t)i;
-        recipe_id.clear();
-        for (material const* m : tables.material_of_prim) recipe_id.push_back(id.at(m));
+    scene_flattener const& tables() const { return scene ? scene->tables() : *flat; }
+
+    // recipe -> objects through the scene API -> tables (-> GPU when `upload`)
+    template <class F> void build(F&& make_recipe, int device, bool upload) {
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](int k) {
+            auto const t1 = std::chrono::steady_clock::now();
+            seconds[k] = std::chrono::duration<double>(t1 - t0).count();
+            t0 = t1;
+        };
+        recipe const rc = make_recipe();
+        lap(0);
+        world = rc.instantiate(mt, &by_prim);
+        lap(1);
+        if (upload) {
+            scene = std::make_unique<device_scene>(*world, device);
+            seconds[2] = scene->flatten_seconds; seconds[3] = scene->create_seconds;
+        } else {
+            flat = std::make_unique<scene_flattener>();
+            world->flatten_items(*flat);
+            lap(2);
+        }
+        desc = tables().desc();
+        if (std::getenv("RTIOW_VERBOSE"))
+            std::fprintf(stderr, "rtiow host: recipe %.3f s, objects and bvh_node build %.3f s, flatten %.3f s, rt_scene_create %.3f s\n", seconds[0], seconds[1], seconds[2], seconds[3]);
+    }
+
+    void number_prims() {
+        if (!recipe_id.empty() || tables().material_of_prim.empty()) return;
+        scene_flattener const& tables = this->tables();
+        // every primitive owns its material: the material's address identifies the primitive
+        std::vector<std::pair<material const*, int32_t>> id(by_prim.size());
+        for (size_t i = 0; i < by_prim.size(); ++i) id[i] = {by_prim[i], (int32_t)i};
+        std::sort(id.begin(), id.end());
+        recipe_id.resize(tables.material_of_prim.size());
+        for (size_t i = 0; i < recipe_id.size(); ++i) {
+            material const* const m = tables.material_of_prim[i];
+            auto const it = std::lower_bound(id.begin(), id.end(), std::make_pair(m, (int32_t)0));
+            if (it == id.end() || it->first != m) throw std::runtime_error("a primitive's material is not one of the recipe's");
+            recipe_id[i] = it->second;
+        }
     }
 };
 
@@ -76,12 +116,7 @@ int rth_world_generate(const char* kind, uint32_t seed, int n, int device, rth_w
     *out = nullptr;
     return guarded([&] {
         auto w = std::make_unique<rth_world>();
-        recipe const rc = generate(kind, seed, n);
-        std::vector<material const*> by_prim;
-        w->world = rc.instantiate(w->mt, &by_prim);
-        w->scene = std::make_unique<device_scene>(*w->world, device);
-        w->desc = w->scene->tables().desc();
-        w->number_prims(w->scene->tables(), by_prim);
+        w->build([&] { return generate(kind, seed, n); }, device, true);
         *out = w.release();
     });
 }
@@ -91,12 +126,7 @@ int rth_world_load(const char* recipe_path, int device, rth_world** out) {
     *out = nullptr;
     return guarded([&] {
         auto w = std::make_unique<rth_world>();
-        recipe const rc = recipe::load(recipe_path);
-        std::vector<material const*> by_prim;
-        w->world = rc.instantiate(w->mt, &by_prim);
-        w->scene = std::make_unique<device_scene>(*w->world, device);
-        w->desc = w->scene->tables().desc();
-        w->number_prims(w->scene->tables(), by_prim);
+        w->build([&] { return recipe::load(recipe_path); }, device, true);
         *out = w.release();
     });
 }
@@ -107,20 +137,20 @@ const rt_scene_desc* rth_world_desc(rth_world* w) { return &w->desc; }
 
 // The tables number primitives in the order the world was flattened (left-to-right leaf
 // order); this gives, for each of them, its number in the recipe (construction order).
-const int32_t* rth_world_recipe_ids(rth_world* w) { return w->recipe_id.data(); }
+const int32_t* rth_world_recipe_ids(rth_world* w) {
+    if (guarded([&] { w->number_prims(); })) return nullptr;
+    return w->recipe_id.data();
+}
+
+// seconds spent in: making the recipe (generator or file), objects + bvh_node build, flatten, rt_scene_create
+void rth_world_seconds(rth_world* w, double* out4) { std::memcpy(out4, w->seconds, sizeof w->seconds); }
 
 // Flattens a recipe's world without touching a GPU: tables only (for host-side checks).
 int rth_world_tables(const char* recipe_path, rth_world** out) {
     *out = nullptr;
     return guarded([&] {
         auto w = std::make_unique<rth_world>();
-        recipe const rc = recipe::load(recipe_path);
-        std::vector<material const*> by_prim;
-        w->world = rc.instantiate(w->mt, &by_prim);
-        w->flat = std::make_unique<scene_flattener>();
-        w->world->flatten_items(*w->flat);
-        w->desc = w->flat->desc();
-        w->number_prims(*w->flat, by_prim);
+        w->build([&] { return recipe::load(recipe_path); }, -1, false);
         *out = w.release();
     });
 }

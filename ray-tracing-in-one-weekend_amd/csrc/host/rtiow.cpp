@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -102,9 +104,13 @@ rt_scene_desc scene_flattener::desc() const {
 }
 
 device_scene::device_scene(object const& world, int device) {
+    auto const t0 = std::chrono::steady_clock::now();
     world.flatten_items(flat);
+    auto const t1 = std::chrono::steady_clock::now();
     rt_scene_desc const d = flat.desc();
     if (rt_scene_create(&d, device, &handle)) device_failure("device_scene");
+    flatten_seconds = std::chrono::duration<double>(t1 - t0).count();
+    create_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
 }
 
 device_scene::~device_scene() { rt_scene_destroy(handle); }

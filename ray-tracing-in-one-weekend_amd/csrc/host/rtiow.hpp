@@ -119,6 +119,7 @@ public:
     device_scene& operator=(device_scene const&) = delete;
     rt_scene* get() const { return handle; }
     scene_flattener const& tables() const { return flat; }
+    double flatten_seconds = 0, create_seconds = 0;   // how long the two halves of the constructor took
 };
 
 // ---- textures (texture.hpp:9-33) -------------------------------------------------------

@@ -1044,6 +1044,11 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
 
     const double t_layout = seconds_since(t_start);
     if (verbose) fprintf(stderr, "rtiow: tree laid out on the host in %.3f s (%zu nodes)\n", t_layout, fl.nodes.size());
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (verbose) fprintf(stderr, "rtiow:   %s %.3f s\n", what, seconds_since(t_lap));
+        t_lap = std::chrono::steady_clock::now();
+    };
     if (rt_device_count() <= 0) return fail(RT_E_DEVICE, "no HIP device available");
     if (int rc = use_device(device, &device)) return rc;
 
@@ -1097,6 +1102,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             spill_ints = (size_t)(stack_depth - cap) * s->n_cus * 256 * kWavesMax;
         }
     }
+    lap("kernel shape, top levels staged");
     s->n_prims_desc = desc->n_prims;
     s->n_textures = desc->n_textures;
     s->material_of_prim.resize(desc->n_prims);
@@ -1131,6 +1137,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         memcpy(perm.data() + 512, desc->perlin_perm_z, 256);
     }
 
+    lap("material and texture tables");
     {   // the address of rt_render_noalloc's working memory on this device, while set-up may still take its time
         unsigned char *unused;
         if (int rc = scratch_on_device(device, &unused)) return rc;
@@ -1147,6 +1154,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (e == hipSuccess) e = s->counter.alloc(kCounters);
     if (e == hipSuccess && spill_ints) e = s->spill.alloc(spill_ints);
     s->spill_ints = spill_ints;
+    lap("upload");
     // the kernels with per-lane stacks may ask for more dynamic LDS than the default 64 KiB limit
     const void *kernels[19] = {
         reinterpret_cast<const void *>(&k_trace_batch),
@@ -1166,6 +1174,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     for (const void *k : kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
+    lap("kernel attributes");
     s->d.nodes = s->nodes.p; s->d.leaves = s->leaves.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
@@ -1225,6 +1234,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
                 s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
                 s->render_lnodes, s->render_lleaves,
                 s->render_stack_cap, s->render_lds_bytes, kLdsBudget, spill_ints * sizeof(int), s->render_defer ? "for the winning leaf" : "up front");
+    if (verbose) fprintf(stderr, "rtiow: scene created in %.3f s (%.3f s of it after the layout: kernel shape, top levels, upload)\n", seconds_since(t_start), seconds_since(t_start) - t_layout);
     *out = owner.release();
     return RT_OK;
 }
