@@ -1,6 +1,5 @@
 #!/bin/bash
-# Hardware-counter passes over one short bench run (one frame each: costing pass + k_render
-# launch), one rocprofv3 process per pass: the counters of a pass must fit the per-block slot
+# Hardware-counter passes over one short bench run (a warm-up frame and a timed one each), one rocprofv3 process per pass: the counters of a pass must fit the per-block slot
 # limits (8 SQ, 4 TCC with FETCH_SIZE = 3 and WRITE_SIZE = 2, 4 TCP, 2 TA, 2 GRBM).
 # usage: tools/pmc_profile.sh OUTDIR [bench args...]   (run from the repository root)
 set -u
@@ -11,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {
     name=$1; shift
     timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$R/$OUT" -o "$name" -- \
-        python3 "$R/bench.py" --steps 1 --warmup 0 --timed-only $BENCH_ARGS > "$R/$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$R/$OUT/$name.log"; exit 1; }
+        python3 "$R/bench.py" --steps 1 --warmup 1 --timed-only $BENCH_ARGS > "$R/$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$R/$OUT/$name.log"; exit 1; }
 }
 BENCH_ARGS="${*:---spp 32}"
 run sq_a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE GRBM_COUNT

@@ -3,8 +3,9 @@
 
 usage: tools/roofline_inputs.py PMC_DIR OUT_DIR CONFIG_KEY TAG
 
-Sums every counter over the k_render dispatches of one frame (costing pass + main launch: what
-rt_stats.kernel_ms times) and writes OUT_DIR/valu.json and OUT_DIR/traffic.json.
+Takes every counter from the last main k_render launch of its pass (the passes run one warm-up frame,
+which measures the tile costs, and one frame like the benchmark's timed ones, which reuses the tile
+order: one launch, what rt_stats.kernel_ms times) and writes OUT_DIR/valu.json and OUT_DIR/traffic.json.
 
 Units (checked against tools/microbench/valu_rates under the same counters): the SQ cycle
 counters tick once per 4 clocks; SQ_THREAD_CYCLES_VALU adds, per VALU instruction pass, the
@@ -17,6 +18,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 N_XCD, N_SIMD = 8, 1024
@@ -24,10 +26,16 @@ N_XCD, N_SIMD = 8, 1024
 
 def main():
     pmc_dir, out_dir, config_key, tag = sys.argv[1:5]
+    # the last main launch of each pass: the frame a timed step renders (tile order on file from the warm-up frame)
     tot, span = {}, {}
+    main_launch = re.compile(r"k_render<\w+, \w+, \d+, false,")
     for f in sorted(glob.glob(os.path.join(pmc_dir, "*_counter_collection.csv"))):
-        for row in csv.DictReader(open(f)):
-            if "k_render" not in row["Kernel_Name"]:
+        rows = [row for row in csv.DictReader(open(f)) if main_launch.search(row["Kernel_Name"])]
+        if not rows:
+            continue
+        last = max(int(row["Dispatch_Id"]) for row in rows)
+        for row in rows:
+            if int(row["Dispatch_Id"]) != last:
                 continue
             tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             if row["Counter_Name"] == "SQ_THREAD_CYCLES_VALU":
@@ -40,7 +48,7 @@ def main():
     clocks = g("GRBM_GUI_ACTIVE") / N_XCD                    # shader clocks the frame's kernels were resident
     lanes = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
     valu = {
-        "config_key": config_key, "source": f"{tag}/pmc1024 (tools/pmc_profile.sh --spp 1024; sums over the frame's k_render dispatches)",
+        "config_key": config_key, "source": f"{tag}/pmc1024 (tools/pmc_profile.sh --spp 1024; the second frame's k_render launch)",
         "SQ_THREAD_CYCLES_VALU": g("SQ_THREAD_CYCLES_VALU"), "SQ_ACTIVE_INST_VALU": g("SQ_ACTIVE_INST_VALU"), "SQ_INSTS_VALU": g("SQ_INSTS_VALU"),
         "SQ_WAVE_CYCLES": g("SQ_WAVE_CYCLES"), "SQ_WAVES": g("SQ_WAVES"), "GRBM_GUI_ACTIVE": g("GRBM_GUI_ACTIVE"),
         "lanes_active": lanes,                                                     # of 64, per VALU instruction
