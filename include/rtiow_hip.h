@@ -144,7 +144,9 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
  * time (use one scene per stream if they must).  Frames of 32 samples per pixel or more are
  * preceded by a short costing pass on the same stream (tiles are then rendered dearest
  * first); its two small device buffers are allocated on the first such call for an image
- * size, which may synchronise the device.  The image does not depend on any of this. */
+ * size, which may synchronise the device.  A frame of the same camera, size and depth limit
+ * as the scene's last costed frame reuses that frame's tile order and skips the pass.  The
+ * image does not depend on any of this. */
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 
