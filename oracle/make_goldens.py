@@ -9,6 +9,7 @@ are what pins the oracle and the GPU path.
 
 Usage: python oracle/make_goldens.py                  (from the repository root; everything)
        python oracle/make_goldens.py --deep-frames    (only tests/golden/frames_1024.npz)
+       python oracle/make_goldens.py --lists          (only tests/golden/scenes/lists.recipe, trace_lists.npz)
 """
 import ctypes
 import json
@@ -104,6 +105,75 @@ sphere 8 -1 0 -2 0.5
 """
 
 
+# object_lists handed to a bvh_node as single objects (bvh_node.cpp:34-40, object_list.cpp:12-48):
+# coincident spheres inside a list (the FIRST member wins, object_list.cpp:18-21), a list member
+# coincident with a sphere outside the list (the bvh's RIGHT child wins, bvh_node.cpp:60-61), a list of
+# one, lists with moving spheres, and a second bvh group that is nothing but one list
+LISTS = """rtiow-recipe 1
+texture constant 0.7 0.7 0.2
+texture constant 0.2 0.4 0.8
+texture chequer 0 1
+""" + "".join(f"material {m}\n" for m in ["lambertian 2", "lambertian 0", "metal 0.8 0.8 0.9 0.1", "dielectric 1.5", "lambertian 1",
+                                              "lambertian 0", "lambertian 1", "metal 0.9 0.5 0.3 0.3", "lambertian 0", "lambertian 1",
+                                              "dielectric 1.4", "lambertian 0", "lambertian 1", "lambertian 0", "metal 0.6 0.9 0.6 0",
+                                              "lambertian 1", "lambertian 0", "lambertian 1"]) + """sphere 0 0 -100.5 -1 100
+bvh_begin 5 0 1
+sphere 1 -2 0 -1 0.5
+list_begin
+sphere 2 0 0 -1 0.5
+sphere 3 0 0 -1 0.5
+sphere 4 0.4 0.1 -0.8 0.3
+list_end
+moving_sphere 5 2 0 -1 2 0.5 -1 0 1 0.4
+list_begin
+sphere 6 -1 0.8 -1.5 0.35
+list_end
+list_begin
+moving_sphere 7 1 1 -2 1.3 1.2 -2 0 1 0.45
+sphere 8 1.1 0.9 -1.9 0.4
+sphere 9 -2 0 -1 0.5
+list_end
+sphere 10 0.6 -0.2 -0.3 0.25
+sphere 11 -0.8 -0.1 -0.4 0.3
+bvh_end
+bvh_begin 9 0 1
+list_begin
+sphere 12 3 0.2 -2 0.6
+sphere 13 3 0.2 -2 0.6
+moving_sphere 14 3.5 0.4 -1.5 3.2 0.9 -1.5 -0.5 1.5 0.3
+sphere 15 2.6 0.5 -2.4 0.4
+list_end
+bvh_end
+sphere 16 -3 0.3 -2 0.7
+sphere 17 -3 0.3 -2 0.7
+"""
+
+
+def lists_scene():
+    """tests/golden/scenes/lists.recipe and tests/golden/trace_lists.npz: hits of the reference on a
+    scene whose bvh groups hold object_lists, and a small frame with the reference's own generator."""
+    with open(os.path.join(SCENES, "lists.recipe"), "w") as f:
+        f.write(LISTS)
+    rng = np.random.default_rng(20251111)
+    cam2 = book_camera(2.0)
+    cam2[0:3] = [1.0, 2.0, 6.0]
+    cam2[3:6] = [0.3, 0.2, -1.5]
+    cam2[9] = 50.0
+    with tempfile.TemporaryDirectory() as tmp:
+        hr, _ = harvest(tmp, "lists", 4242, 48, 24, 3, cam2, 10 ** 7)
+        rays = np.vstack([hr[np.sort(rng.permutation(len(hr))[:2500])], random_rays(rng, 4000, np.array([0.3, 0.3, -1.3]), 3.5)])
+        exp = trace(tmp, "lists", rays, 0.001, None)
+        sub = rays[-1500:]
+        exp2 = trace(tmp, "lists", sub, 0.25, 6.5)
+        img = os.path.join(tmp, "img.bin")
+        run("render", os.path.join(SCENES, "lists.recipe"), 31337, 48, 24, 3, *cam2, img)
+        frame = get(img, 3).reshape(24, 48, 3)
+    np.savez_compressed(os.path.join(GOLD, "trace_lists.npz"), rays=rays, tmin=0.001, tmax=np.finfo(np.float64).max, expected=exp,
+                        rays2=sub, tmin2=0.25, tmax2=6.5, expected2=exp2, camera=np.array(cam2), frame_exact=frame)
+    prims = exp[exp[:, 0] > 0, 1].astype(int)
+    return {"rays": len(rays), "hits": int(exp[:, 0].sum()), "prims_hit": sorted(set(prims.tolist()))}
+
+
 def write_scenes():
     os.makedirs(SCENES, exist_ok=True)
     host = ctypes.CDLL(HOST)
@@ -164,6 +234,15 @@ def deep_frames():
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_capture is missing: run `make -C oracle` where /root/reference exists")
+    if sys.argv[1:] == ["--lists"]:            # only the scene with object_lists below bvh_nodes
+        info = lists_scene()
+        path = os.path.join(GOLD, "manifest.json")
+        manifest = json.load(open(path))
+        manifest["trace_lists"] = info
+        with open(path, "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print(json.dumps(info))
+        return
     if sys.argv[1:] == ["--deep-frames"]:      # only the 1024-spp frames (the slow part), leaving the rest as committed
         shapes = deep_frames()
         path = os.path.join(GOLD, "manifest.json")
@@ -298,6 +377,7 @@ def main():
         np.savez_compressed(os.path.join(GOLD, "frames.npz"), camera=np.array(cam2), **frames)
         manifest["frames"] = {k: list(v.shape) for k, v in frames.items()}
     manifest["frames_1024"] = deep_frames()
+    manifest["trace_lists"] = lists_scene()
 
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

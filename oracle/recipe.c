@@ -11,10 +11,13 @@
  *   sphere MAT CX CY CZ R
  *   moving_sphere MAT C0X C0Y C0Z C1X C1Y C1Z T0 T1 R
  *   bvh_begin SEED T0 T1   ... primitives ...   bvh_end
+ *   list_begin   ... primitives ...   list_end            (inside a bvh group only)
  *
  * Textures, materials and primitives are numbered from 0 in order of appearance.
  * The top level is an object_list; a bvh group is one bvh_node built over its
- * primitives with a fresh std::mt19937(SEED).
+ * objects with a fresh std::mt19937(SEED).  A list group inside a bvh group is one
+ * object_list handed to that bvh_node as a single object (object_list.cpp:28-48 gives
+ * it a bounding box for exactly that).
  */
 #include "rt_oracle.h"
 
@@ -39,7 +42,7 @@ static void fail(char *err, size_t errlen, const char *fmt, ...) {
 
 void orc_scene_free(oscene *s) {
     if (!s) return;
-    free(s->tex); free(s->mat); free(s->prim); free(s->node); free(s->item);
+    free(s->tex); free(s->mat); free(s->prim); free(s->list); free(s->node); free(s->item);
     free(s);
 }
 
@@ -48,7 +51,7 @@ oscene *orc_scene_load(const char *path, char *err, size_t errlen) {
     if (!f) { fail(err, errlen, "cannot open %s", path); return NULL; }
     oscene *s = (oscene *)calloc(1, sizeof(oscene));
     char line[1024];
-    int lineno = 0, in_bvh = 0, header = 0;
+    int lineno = 0, in_bvh = 0, in_list = 0, header = 0;
     oitem group;
     memset(&group, 0, sizeof group);
     while (fgets(line, sizeof line, f)) {
@@ -111,6 +114,8 @@ oscene *orc_scene_load(const char *path, char *err, size_t errlen) {
                     goto syntax;
             }
             if (p.mat < 0 || p.mat >= s->n_mat) goto syntax;
+            p.list = in_list ? s->n_list - 1 : -1;
+            if (in_list) s->list[s->n_list - 1].n++;
             GROW(s->prim, s->n_prim, oprim);
             s->prim[s->n_prim++] = p;
             if (in_bvh) {
@@ -129,8 +134,17 @@ oscene *orc_scene_load(const char *path, char *err, size_t errlen) {
             if (sscanf(line, "%*s %lu %lf %lf", &seed, &group.t0, &group.t1) != 3) goto syntax;
             group.is_bvh = 1; group.seed = (uint32_t)seed; group.first_prim = s->n_prim;
             in_bvh = 1;
+        } else if (strcmp(kw, "list_begin") == 0) {
+            if (!in_bvh || in_list) goto syntax;
+            olist l = {s->n_prim, 0};
+            GROW(s->list, s->n_list, olist);
+            s->list[s->n_list++] = l;
+            in_list = 1;
+        } else if (strcmp(kw, "list_end") == 0) {
+            if (!in_list || s->list[s->n_list - 1].n == 0) goto syntax;
+            in_list = 0;
         } else if (strcmp(kw, "bvh_end") == 0) {
-            if (!in_bvh || group.n_prims == 0) goto syntax;
+            if (!in_bvh || in_list || group.n_prims == 0) goto syntax;
             in_bvh = 0;
             GROW(s->item, s->n_item, oitem);
             s->item[s->n_item++] = group;
@@ -146,11 +160,17 @@ oscene *orc_scene_load(const char *path, char *err, size_t errlen) {
     for (int i = 0; i < s->n_item; ++i) {
         oitem *it = &s->item[i];
         if (!it->is_bvh) continue;
+        /* the group's objects: its primitives, a list counting as one */
         int *ids = (int *)malloc((size_t)it->n_prims * sizeof(int));
-        for (int k = 0; k < it->n_prims; ++k) ids[k] = it->first_prim + k;
+        int n = 0;
+        for (int k = 0; k < it->n_prims; ++k) {
+            const oprim *p = &s->prim[it->first_prim + k];
+            if (p->list < 0) ids[n++] = it->first_prim + k;
+            else if (s->list[p->list].first == it->first_prim + k) ids[n++] = ORC_LIST_BASE + p->list;
+        }
         omt19937 mt;
         orc_mt_seed(&mt, it->seed);
-        it->index = orc_bvh_build(s, ids, it->n_prims, &mt, it->t0, it->t1);
+        it->index = orc_bvh_build(s, ids, n, &mt, it->t0, it->t1);
         free(ids);
     }
     return s;

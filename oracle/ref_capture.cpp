@@ -124,8 +124,16 @@ built_scene build(const char *recipe_path, std::mt19937 &mt) {
         if (!it.is_bvh) {
             items.push_back(make_prim(b, it.first_prim, mt));
         } else {
+            // the group's objects: its primitives, the members of a list group as one object_list
             std::vector<std::unique_ptr<object const>> objs;
-            for (int k = 0; k < it.n_prims; ++k) objs.push_back(make_prim(b, it.first_prim + k, mt));
+            for (int k = 0; k < it.n_prims;) {
+                const int list = b.recipe->prim[it.first_prim + k].list;
+                if (list < 0) { objs.push_back(make_prim(b, it.first_prim + k, mt)); ++k; continue; }
+                std::vector<std::unique_ptr<object const>> members;
+                for (int m = 0; m < b.recipe->list[list].n; ++m) members.push_back(make_prim(b, b.recipe->list[list].first + m, mt));
+                objs.push_back(std::make_unique<object_list const>(std::move(members)));
+                k += b.recipe->list[list].n;
+            }
             std::mt19937 bm(it.seed);
             auto node = std::make_unique<bvh_node const>(bm, objs, it.t0, it.t1);
             b.bvh_roots.push_back(node.get());

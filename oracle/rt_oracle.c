@@ -379,11 +379,35 @@ void orc_introsort(int *v, int n, less_fn less, void *ctx) {
 /* ------------------------------------------------------------------- bvh ---- */
 typedef struct { const oscene *s; int axis; double t0, t1; } sortctx;
 
+/* object_list::bounding_box (object_list.cpp:28-48): the first member's box, joined with each
+ * further member's in order (a list inside a bvh group is never empty: the recipe reader refuses one) */
+static oaabb list_bbox(const oscene *s, const olist *l, double t0, double t1) {
+    oaabb b = orc_prim_bbox(&s->prim[l->first], t0, t1);
+    for (int k = 1; k < l->n; ++k) b = orc_surrounding_box(b, orc_prim_bbox(&s->prim[l->first + k], t0, t1));
+    return b;
+}
+
+/* bounding box of an object of a bvh group: a primitive or a list */
+static oaabb object_bbox(const oscene *s, int obj, double t0, double t1) {
+    return obj >= ORC_LIST_BASE ? list_bbox(s, &s->list[obj - ORC_LIST_BASE], t0, t1) : orc_prim_bbox(&s->prim[obj], t0, t1);
+}
+
+/* object_list::hit (object_list.cpp:12-26) for a list below a bvh_node: linear scan, the upper
+ * bound narrows to the closest hit so far, a later equal t does not replace it */
+static int list_hit(const oscene *s, const olist *l, const oray *r, double tmin, double tmax, ohit *out) {
+    int any = 0;
+    double closest = tmax;
+    ohit h;
+    for (int k = 0; k < l->n; ++k)
+        if (orc_prim_hit(s, l->first + k, r, tmin, closest, &h)) { any = 1; closest = h.t; *out = h; }
+    return any;
+}
+
 /* bvh_node.cpp:10-28: compare the box minimum on the chosen axis */
 static int box_min_less(int l, int r, void *vctx) {
     sortctx *c = (sortctx *)vctx;
-    oaabb bl = orc_prim_bbox(&c->s->prim[l], c->t0, c->t1);
-    oaabb br = orc_prim_bbox(&c->s->prim[r], c->t0, c->t1);
+    oaabb bl = object_bbox(c->s, l, c->t0, c->t1);
+    oaabb br = object_bbox(c->s, r, c->t0, c->t1);
     switch (c->axis) {
     case 0: return bl.mn.x < br.mn.x;
     case 1: return bl.mn.y < br.mn.y;
@@ -400,7 +424,7 @@ static int alloc_node(oscene *s) {
 }
 
 static oaabb child_box(const oscene *s, int ref, double t0, double t1) {
-    return ref >= 0 ? s->node[ref].box : orc_prim_bbox(&s->prim[~ref], t0, t1);
+    return ref >= 0 ? s->node[ref].box : object_bbox(s, ~ref, t0, t1);
 }
 
 /* bvh_node.cpp:8-50.  Draw the axis, sort the span in place, then: one object ->
@@ -427,7 +451,9 @@ int orc_bvh_build(oscene *s, int *prims, int n, omt19937 *mt, double t0, double 
 }
 
 static int child_hit(const oscene *s, int ref, const oray *r, double tmin, double tmax, ohit *out) {
-    return ref >= 0 ? orc_bvh_hit(s, ref, r, tmin, tmax, out) : orc_prim_hit(s, ~ref, r, tmin, tmax, out);
+    if (ref >= 0) return orc_bvh_hit(s, ref, r, tmin, tmax, out);
+    if (~ref >= ORC_LIST_BASE) return list_hit(s, &s->list[~ref - ORC_LIST_BASE], r, tmin, tmax, out);
+    return orc_prim_hit(s, ~ref, r, tmin, tmax, out);
 }
 
 /* bvh_node.cpp:52-69: box test, then BOTH children with the same interval; the

@@ -35,8 +35,12 @@ enum { ORC_PRIM_SPHERE = 0, ORC_PRIM_MOVING_SPHERE = 1 };
 
 typedef struct { int kind; double c[3]; int even, odd; } otexture;
 typedef struct { int kind; int tex; double albedo[3]; double fuzz; double ri; } omaterial;
-typedef struct { int kind; ovec3 c0, c1; double t0, t1, r; int mat; } oprim;
-/* child reference: >= 0 -> node index, < 0 -> ~prim index */
+typedef struct { int kind; ovec3 c0, c1; double t0, t1, r; int mat; int list; /* object_list it belongs to inside a bvh group, -1 = none */ } oprim;
+/* an object_list handed to a bvh_node as one of its objects (object_list.hpp:8-17): primitives [first, first + n) */
+typedef struct { int first, n; } olist;
+/* An object of a bvh group is a primitive (its index) or a list (ORC_LIST_BASE + its index).
+ * child reference of a node: >= 0 -> node index, < 0 -> ~object */
+enum { ORC_LIST_BASE = 1 << 30 };
 typedef struct { oaabb box; int left, right; } onode;
 /* one entry of the top-level object_list: a primitive or the root of a bvh_node */
 typedef struct { int is_bvh; int index; uint32_t seed; double t0, t1; int first_prim, n_prims; } oitem;
@@ -45,6 +49,7 @@ typedef struct {
     otexture *tex;  int n_tex;
     omaterial *mat; int n_mat;
     oprim *prim;    int n_prim;
+    olist *list;    int n_list;
     onode *node;    int n_node, cap_node;
     oitem *item;    int n_item;
 } oscene;

@@ -27,10 +27,10 @@ int recipe::add_dielectric(double ri) {
     return (int)materials.size() - 1;
 }
 void recipe::add_sphere(int m, double x, double y, double z, double r) {
-    prims.push_back({RT_PRIM_SPHERE, m, {x, y, z}, {x, y, z}, 0, 1, r});
+    prims.push_back({RT_PRIM_SPHERE, m, {x, y, z}, {x, y, z}, 0, 1, r, -1});
 }
 void recipe::add_moving_sphere(int m, double const c0[3], double const c1[3], double t0, double t1, double r) {
-    prims.push_back({RT_PRIM_MOVING_SPHERE, m, {c0[0], c0[1], c0[2]}, {c1[0], c1[1], c1[2]}, t0, t1, r});
+    prims.push_back({RT_PRIM_MOVING_SPHERE, m, {c0[0], c0[1], c0[2]}, {c1[0], c1[1], c1[2]}, t0, t1, r, -1});
 }
 
 void recipe::save(std::string const& path) const {
@@ -56,7 +56,17 @@ void recipe::save(std::string const& path) const {
     };
     for (item const& it : items) {
         if (it.is_bvh) std::fprintf(f, "bvh_begin %u %.17g %.17g\n", it.seed, it.t0, it.t1);
-        for (int k = 0; k < it.count; ++k) put_prim(prims[(size_t)(it.first + k)]);
+        int open_list = -1;
+        for (int k = 0; k < it.count; ++k) {
+            prim const& p = prims[(size_t)(it.first + k)];
+            if (p.list != open_list) {
+                if (open_list >= 0) std::fprintf(f, "list_end\n");
+                if (p.list >= 0) std::fprintf(f, "list_begin\n");
+                open_list = p.list;
+            }
+            put_prim(p);
+        }
+        if (open_list >= 0) std::fprintf(f, "list_end\n");
         if (it.is_bvh) std::fprintf(f, "bvh_end\n");
     }
     std::fclose(f);
@@ -116,7 +126,8 @@ recipe recipe::load(std::string const& path) {
     recipe rc;
     char line[1024], kw[64], sub[64];
     int lineno = 0;
-    bool header = false, in_bvh = false;
+    bool header = false, in_bvh = false, in_list = false;
+    int list_members = 0;
     item group{};
     auto bad = [&](char const* why) {
         std::fclose(f);
@@ -188,6 +199,8 @@ recipe recipe::load(std::string const& path) {
                 p.t0 = v[6]; p.t1 = v[7]; p.r = v[8];
             }
             if (p.mat < 0 || p.mat >= (int)rc.materials.size()) bad("material out of range");
+            p.list = in_list ? rc.n_lists - 1 : -1;
+            if (in_list) ++list_members;
             rc.prims.push_back(p);
             if (in_bvh) group.count++;
             else rc.items.push_back({false, 0, 0, 0, (int)rc.prims.size() - 1, 1});
@@ -198,7 +211,16 @@ recipe recipe::load(std::string const& path) {
             if (std::sscanf(line, "%*s %lu %lf %lf", &seed, &group.t0, &group.t1) != 3) bad("bvh_begin needs SEED T0 T1");
             group.is_bvh = true; group.seed = (uint32_t)seed; group.first = (int)rc.prims.size();
             in_bvh = true;
+        } else if (!std::strcmp(kw, "list_begin")) {
+            if (!in_bvh || in_list) bad("list_begin outside a bvh group, or nested");
+            in_list = true;
+            list_members = 0;
+            ++rc.n_lists;
+        } else if (!std::strcmp(kw, "list_end")) {
+            if (!in_list || list_members == 0) bad("list_end without primitives");
+            in_list = false;
         } else if (!std::strcmp(kw, "bvh_end")) {
+            if (in_list) bad("bvh_end inside a list group");
             if (!in_bvh || group.count == 0) bad("bvh_end without primitives");
             in_bvh = false;
             rc.items.push_back(group);
@@ -243,9 +265,16 @@ std::unique_ptr<object const> recipe::instantiate(std::mt19937& mt, std::vector<
             world.push_back(make_prim(*this, it.first, mt, by_prim));
             continue;
         }
+        // the group's objects: its primitives, the members of a list group as one object_list
         std::vector<std::unique_ptr<object const>> objs;
         objs.reserve((size_t)it.count);
-        for (int k = 0; k < it.count; ++k) objs.push_back(make_prim(*this, it.first + k, mt, by_prim));
+        for (int k = 0; k < it.count;) {
+            int const list = prims[(size_t)(it.first + k)].list;
+            if (list < 0) { objs.push_back(make_prim(*this, it.first + k, mt, by_prim)); ++k; continue; }
+            std::vector<std::unique_ptr<object const>> members;
+            for (; k < it.count && prims[(size_t)(it.first + k)].list == list; ++k) members.push_back(make_prim(*this, it.first + k, mt, by_prim));
+            objs.push_back(std::make_unique<object_list const>(std::move(members)));
+        }
         std::mt19937 bm(it.seed);
         world.push_back(std::make_unique<bvh_node const>(bm, objs, it.t0, it.t1));
     }

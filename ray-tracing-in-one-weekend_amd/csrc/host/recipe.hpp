@@ -8,10 +8,12 @@
 //   sphere MAT CX CY CZ R
 //   moving_sphere MAT C0X C0Y C0Z C1X C1Y C1Z T0 T1 R
 //   bvh_begin SEED T0 T1 ... primitives ... bvh_end
+//   list_begin ... primitives ... list_end               (inside a bvh group only)
 //
 // Textures, materials and primitives are numbered from 0 in order of appearance.  The
-// top level is an object_list; a bvh group is one bvh_node built over its primitives
-// with a fresh std::mt19937(SEED).
+// top level is an object_list; a bvh group is one bvh_node built over its objects with a
+// fresh std::mt19937(SEED); a list group inside it is one object_list handed to that
+// bvh_node as a single object.
 #pragma once
 
 #include <cstdint>
@@ -27,13 +29,14 @@ namespace rtiow {
 struct recipe {
     struct tex { int kind; double c[3]; int even, odd; };
     struct mat { int kind; int tex; double albedo[3]; double fuzz, ri; };
-    struct prim { int kind; int mat; double c0[3], c1[3], t0, t1, r; };
+    struct prim { int kind; int mat; double c0[3], c1[3], t0, t1, r; int list = -1; };   // list: the list group it belongs to, -1 = none
     struct item { bool is_bvh; uint32_t seed; double t0, t1; int first, count; };
 
     std::vector<tex> textures;
     std::vector<mat> materials;
     std::vector<prim> prims;
     std::vector<item> items;
+    int n_lists = 0;
 
     static recipe load(std::string const& path);   // throws std::runtime_error
     void save(std::string const& path) const;

@@ -155,7 +155,7 @@ class probe_object final : public object {
 public:
     explicit probe_object(material const& m) : m(m) {}
     std::optional<aabb> bounding_box(double, double) const override { return aabb(vec3{-1, -1, -1}, vec3{1, 1, 1}); }
-    int32_t flatten_child(scene_flattener& out) const override {
+    int32_t flatten_child(scene_flattener& out, aabb const&) const override {
         rt_prim_desc p{};
         p.kind = RT_PRIM_SPHERE;
         p.material = m.flatten(out);
@@ -303,8 +303,11 @@ uint32_t dielectric::flatten(scene_flattener& out) const {
 object::object() = default;
 object::~object() = default;
 
+void object::scan_members(std::vector<object const*>& out) const { out.push_back(this); }
+
 void object::flatten_items(scene_flattener& out) const {
-    int32_t const ref = flatten_child(out);
+    // (only a list looks at its parent's box, and a list appends its members as items instead)
+    int32_t const ref = flatten_child(out, aabb(vec3{0, 0, 0}, vec3{0, 0, 0}));
     rt_item_desc it{};
     it.is_bvh = ref >= 0;
     it.index = ref >= 0 ? ref : ~ref;
@@ -330,7 +333,7 @@ std::optional<aabb> sphere::bounding_box(double, double) const {
     return aabb(centre - rv, centre + rv);
 }
 
-int32_t sphere::flatten_child(scene_flattener& out) const {
+int32_t sphere::flatten_child(scene_flattener& out, aabb const&) const {
     rt_prim_desc p{};
     p.kind = RT_PRIM_SPHERE;
     p.material = mat->flatten(out);
@@ -361,7 +364,7 @@ std::optional<aabb> moving_sphere::bounding_box(double const t0, double const t1
     return aabb::surrounding_box(box0, box1);
 }
 
-int32_t moving_sphere::flatten_child(scene_flattener& out) const {
+int32_t moving_sphere::flatten_child(scene_flattener& out, aabb const&) const {
     rt_prim_desc p{};
     p.kind = RT_PRIM_MOVING_SPHERE;
     p.material = mat->flatten(out);
@@ -390,8 +393,41 @@ std::optional<aabb> object_list::bounding_box(double t0, double t1) const {
     return result;
 }
 
-int32_t object_list::flatten_child(scene_flattener&) const {
-    throw std::runtime_error("object_list below a bvh_node is not supported by the GPU scene layout");
+// A list as the child of a bvh_node (bvh_node.cpp:34-40 accepts any object with a box, and
+// object_list.cpp:28-48 gives a list one).  The reference tests the node's box (bvh_node.cpp:53) and
+// then scans the list (object_list.cpp:12-26): every member is tried -- a list tests no box of its
+// own -- the nearest hit wins, and of equal hits the first member's, because a later one must be
+// strictly nearer.  In the tables that is a subtree of nodes that all carry the PARENT's box (testing
+// it again decides nothing new) over the members in REVERSE order: a node prefers its right child on
+// equal hits (bvh_node.cpp:60-61), so the member written last in the subtree -- the list's first --
+// wins among equals, and against the rest of the tree the subtree stands where the list stood.
+namespace {
+int32_t list_subtree(scene_flattener& out, aabb const& box, std::span<object const* const> members) {
+    if (members.size() == 1) return members[0]->flatten_child(out, box);
+    int32_t const me = (int32_t)out.nodes.size();
+    out.nodes.emplace_back();
+    size_t const half = members.size() / 2;
+    int32_t const l = list_subtree(out, box, members.subspan(0, half));
+    int32_t const r = list_subtree(out, box, members.subspan(half));
+    rt_node_desc n{};
+    n.box_min[0] = box.min().x(); n.box_min[1] = box.min().y(); n.box_min[2] = box.min().z();
+    n.box_max[0] = box.max().x(); n.box_max[1] = box.max().y(); n.box_max[2] = box.max().z();
+    n.left = l; n.right = r;
+    out.nodes[(size_t)me] = n;
+    return me;
+}
+}  // namespace
+
+int32_t object_list::flatten_child(scene_flattener& out, aabb const& parent_box) const {
+    std::vector<object const*> members;
+    scan_members(members);
+    if (members.empty()) throw std::runtime_error("an empty object_list below a bvh_node has no bounding box");
+    std::reverse(members.begin(), members.end());
+    return list_subtree(out, parent_box, members);
+}
+
+void object_list::scan_members(std::vector<object const*>& out) const {
+    for (auto const& o : objects) o->scan_members(out);
 }
 
 // A list scans its members in order, each seeing the interval narrowed by the ones
@@ -511,7 +547,7 @@ bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object cons
 std::optional<aabb> bvh_node::bounding_box(double, double) const { return box; }
 
 // Nodes are numbered in pre-order: a node, its whole left subtree, its right subtree.
-int32_t bvh_node::flatten_child(scene_flattener& out) const {
+int32_t bvh_node::flatten_child(scene_flattener& out, aabb const&) const {
     // room for the whole subtree at once: growing the tables of a 10^6-sphere world by doubling
     // copies them several times over (a sphere brings one primitive, one material and at most a
     // few textures; only the root of a large tree finds the capacity short)
@@ -524,8 +560,8 @@ int32_t bvh_node::flatten_child(scene_flattener& out) const {
     }
     int32_t const me = (int32_t)out.nodes.size();
     out.nodes.emplace_back();
-    int32_t const l = left->flatten_child(out);
-    int32_t const r = (right == left) ? l : right->flatten_child(out);
+    int32_t const l = left->flatten_child(out, *box);
+    int32_t const r = (right == left) ? l : right->flatten_child(out, *box);
     rt_node_desc n{};
     n.box_min[0] = box->min().x(); n.box_min[1] = box->min().y(); n.box_min[2] = box->min().z();
     n.box_max[0] = box->max().x(); n.box_max[1] = box->max().y(); n.box_max[2] = box->max().z();

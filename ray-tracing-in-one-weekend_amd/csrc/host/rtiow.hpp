@@ -223,8 +223,11 @@ public:
     virtual std::optional<hit_record> hit(ray const& r, double t_min, double t_max) const;
     virtual std::optional<aabb> bounding_box(double t0, double t1) const = 0;
     // Appends this object to the tables as a bvh child: returns a node index (>= 0) or
-    // ~primitive index.
-    virtual int32_t flatten_child(scene_flattener& out) const = 0;
+    // ~primitive index.  `parent_box` is the box of the bvh_node whose child it is.
+    virtual int32_t flatten_child(scene_flattener& out, aabb const& parent_box) const = 0;
+    // The objects a list scan visits in this object's place, in order: the object itself, or --
+    // for a list -- its members (a list in a list scans like its members written out in place).
+    virtual void scan_members(std::vector<object const*>& out) const;
     // Appends this object to the world's item list.
     virtual void flatten_items(scene_flattener& out) const;
 };
@@ -236,7 +239,7 @@ class sphere final : public object {
 public:
     sphere(vec3 centre, double radius, std::unique_ptr<material const> mat);
     std::optional<aabb> bounding_box(double t0, double t1) const override;
-    int32_t flatten_child(scene_flattener& out) const override;
+    int32_t flatten_child(scene_flattener& out, aabb const& parent_box) const override;
 };
 
 class moving_sphere final : public object {
@@ -248,7 +251,7 @@ class moving_sphere final : public object {
 public:
     moving_sphere(vec3 centre0, vec3 centre1, double time0, double time1, double radius, std::unique_ptr<material const> mat);
     std::optional<aabb> bounding_box(double t0, double t1) const override;
-    int32_t flatten_child(scene_flattener& out) const override;
+    int32_t flatten_child(scene_flattener& out, aabb const& parent_box) const override;
 };
 
 class object_list final : public object {
@@ -257,8 +260,9 @@ public:
     explicit object_list(std::unique_ptr<object const> object);
     explicit object_list(std::vector<std::unique_ptr<object const>> objects);
     std::optional<aabb> bounding_box(double t0, double t1) const override;
-    int32_t flatten_child(scene_flattener& out) const override;
+    int32_t flatten_child(scene_flattener& out, aabb const& parent_box) const override;
     void flatten_items(scene_flattener& out) const override;
+    void scan_members(std::vector<object const*>& out) const override;
 };
 
 class bvh_node final : public object {
@@ -280,7 +284,7 @@ public:
     // a string literal when an object has no bounding box.
     bvh_node(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double t0, double t1);
     std::optional<aabb> bounding_box(double t0, double t1) const override;
-    int32_t flatten_child(scene_flattener& out) const override;
+    int32_t flatten_child(scene_flattener& out, aabb const& parent_box) const override;
 };
 
 // ---- camera, supersampler (camera.hpp:7-28, supersampler.hpp:5-14) ---------------------

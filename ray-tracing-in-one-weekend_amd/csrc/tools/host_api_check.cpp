@@ -56,7 +56,7 @@ int replay(std::mt19937 before, std::mt19937 const& after, double* out, int kmax
 class boxless final : public object {
 public:
     std::optional<aabb> bounding_box(double, double) const override { return std::nullopt; }
-    int32_t flatten_child(scene_flattener&) const override { return 0; }
+    int32_t flatten_child(scene_flattener&, aabb const&) const override { return 0; }
 };
 
 }  // namespace

@@ -38,3 +38,5 @@ def recipe(name):
 
 
 TRACE_SCENES = ["book1", "book2", "stress4096", "two_perlin", "mixed", "ties"]
+# ... and one whose bvh groups hold object_lists (no topology fixture: the reference's tree has list objects as leaves)
+HIT_SCENES = TRACE_SCENES + ["lists"]

@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TRACE_SCENES, golden, recipe
+from conftest import HIT_SCENES, TRACE_SCENES, golden, recipe
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def test_uploaded_tree_is_the_reference_tree(worlds, scene):
     assert np.array_equal(nodes, golden("trace_" + scene)["topology"])
 
 
-@pytest.mark.parametrize("scene", TRACE_SCENES)
+@pytest.mark.parametrize("scene", HIT_SCENES)
 def test_object_hit(worlds, scene):
     g = golden("trace_" + scene)
     w = worlds(scene)
@@ -254,12 +254,12 @@ def test_camera_get_ray(rt):
         assert np.array_equal(out, exp[:, 0:7])
 
 
-FRAME_CASES = [("two_perlin", 48, 24, 6), ("book1", 64, 32, 8), ("book2", 64, 32, 8), ("mixed", 40, 40, 8), ("ties", 33, 17, 4)]
+FRAME_CASES = [("two_perlin", 48, 24, 6), ("book1", 64, 32, 8), ("book2", 64, 32, 8), ("mixed", 40, 40, 8), ("ties", 33, 17, 4), ("lists", 48, 24, 8)]
 
 
 @pytest.mark.parametrize("scene,nx,ny,ns", FRAME_CASES)
 def test_frame_matches_oracle_on_the_same_streams(rt, orc, worlds, scene, nx, ny, ns):
-    cam15 = np.array(golden("frames")["camera"])
+    cam15 = np.array(golden("trace_lists")["camera"] if scene == "lists" else golden("frames")["camera"])
     cam15[10] = nx / ny
     got, stats = worlds(scene).render(rt.camera(cam15), nx, ny, 0, ns, 2025, rt.RT_ACCUM_F64)
     exp, counters = orc.Scene(recipe(scene)).render(cam15, nx, ny, 0, ns, 2025, orc.ORC_RNG_STREAM)
@@ -435,7 +435,7 @@ def test_million_sphere_tree(rt, orc, tmp_path):
     w.close()
 
 
-@pytest.mark.parametrize("scene", ["book1", "book2", "stress4096", "mixed", "ties"])
+@pytest.mark.parametrize("scene", ["book1", "book2", "stress4096", "mixed", "ties", "lists"])
 def test_reclustered_tree_equals_reference_layout(rt, scene, monkeypatch):
     # The device tree is re-clustered over the reference's leaves (surface-area heuristic); with
     # RTIOW_TREE=reference the reference's own topology is uploaded instead.  Both must give the

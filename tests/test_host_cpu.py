@@ -39,6 +39,34 @@ def test_host_bvh_build_matches_reference_tree(rt, scene):
     assert len(items) >= 1
 
 
+def test_object_list_below_a_bvh_node_is_flattened_into_its_parents_box(rt, orc):
+    # A list that is an object of a bvh_node becomes a subtree whose nodes all carry the box of the
+    # node the list hangs from (the reference tests that box, then scans the list: object_list.cpp:12-26),
+    # over the members in reverse order (of equal hits a node keeps its right child's, a list its first member's).
+    nodes, items = rt.world_tables(recipe("lists"))
+    ref = orc.Scene(recipe("lists")).nodes()            # the reference's tree: a list is one leaf object
+    assert len(nodes) > len(ref) and len(items) == 5
+    ref_boxes = {tuple(b) for b in ref[:, :6]}
+    assert all(tuple(n[:6]) in ref_boxes for n in nodes)   # no box that the reference's tree does not have
+    prims = sorted(int(~int(c)) for n in nodes for c in n[6:8] if c < 0)
+    assert sorted(set(prims)) == list(range(1, 16))         # every sphere of the two groups, once each (bare spheres are items)
+    # the list of three under the first group: members 2, 3, 4 appear in reverse order, left to right
+    order = [int(~int(c)) for n in nodes for c in n[6:8] if c < 0 and int(~int(c)) in (2, 3, 4)]
+    assert order == [4, 3, 2]
+
+
+def test_parallel_bvh_build_equals_serial_build(rt, orc, tmp_path, monkeypatch):
+    # halves of large nodes are built by different threads from axes drawn up front: same tree
+    path = str(tmp_path / "s.recipe")
+    rt.generate("stress", 3, path, n=70000)
+    monkeypatch.setenv("RTIOW_BUILD_DEPTH", "0")
+    serial, _ = rt.world_tables(path)
+    monkeypatch.delenv("RTIOW_BUILD_DEPTH")
+    parallel, _ = rt.world_tables(path)
+    assert np.array_equal(serial, parallel) and len(serial) > 60000
+    assert np.array_equal(serial, orc.Scene(path).nodes())   # = the oracle's restatement of bvh_node.cpp:8-50
+
+
 def test_perlin_tables_match_reference_sequence(rt, orc):
     for a, b in zip(rt.perlin_tables(), orc.perlin_tables()):
         assert np.array_equal(a, b)

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import TRACE_SCENES, golden, recipe
+from conftest import HIT_SCENES, TRACE_SCENES, golden, recipe
 
 
 def test_mt19937_known_answer(orc):
@@ -59,7 +59,7 @@ def test_bvh_topology(orc, scene):
     assert np.array_equal(nodes, g["topology"])   # boxes bit-exact, children identical
 
 
-@pytest.mark.parametrize("scene", TRACE_SCENES)
+@pytest.mark.parametrize("scene", HIT_SCENES)
 def test_object_hit(orc, scene):
     g = golden("trace_" + scene)
     s = orc.Scene(recipe(scene))
@@ -125,6 +125,16 @@ def test_frame_bit_exact(orc, scene):
     sums, counters = s.render(g["camera"], 48, 24, 0, 3, 31337, orc.ORC_RNG_MT)
     assert np.array_equal(sums / 3, exp)
     assert counters.paths == 48 * 24 * 3 and counters.rays >= counters.paths
+
+
+def test_frame_bit_exact_with_lists_below_bvh_nodes(orc):
+    # object_lists as objects of a bvh_node (bvh_node.cpp:34-40, object_list.cpp:12-48)
+    g = golden("trace_lists")
+    sums, counters = orc.Scene(recipe("lists")).render(g["camera"], 48, 24, 0, 3, 31337, orc.ORC_RNG_MT)
+    assert np.array_equal(sums / 3, g["frame_exact"])
+    prims = g["expected"][g["expected"][:, 0] > 0, 1].astype(int)
+    # of coincident spheres a list keeps its first member (2 not 3, 12 not 13, 16 not 17)
+    assert {2, 12, 16} <= set(prims) and not {3, 13, 17} & set(prims)
 
 
 def test_stream_mode_matches_mt_mode_statistically(orc):
