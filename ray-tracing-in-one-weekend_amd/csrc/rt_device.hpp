@@ -151,6 +151,24 @@ __device__ __forceinline__ v3 vunit(v3 a) { return vdiv(a, vlen(a)); }
 
 struct Ray { v3 o, d; double time; };
 
+// Division by a denominator that many divisions share.  The IEEE division sequence of the hardware
+// (v_div_scale, v_rcp, two Newton steps on the reciprocal, quotient, remainder, v_div_fmas, v_div_fixup)
+// spends most of its instructions on the denominator alone.  refined_rcp is that part; with it, and
+// when nothing needs scaling or fixing up (finite operands, quotient well inside the normal range, or
+// a zero numerator), the rest of the sequence is q = n y corrected once by its own remainder -- the
+// same operations on the same values, hence the same correctly rounded quotient
+// (tools/division_check.hip compares the two over 10^9 numerators for image sizes up to 2^16).
+__device__ __forceinline__ double refined_rcp(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ double div_by_shared(double n, double d, double rcp_d) {
+    const double q = n * rcp_d;
+    return __builtin_fma(__builtin_fma(-d, q, n), rcp_d, q);
+}
+
 // per-segment constants of the slab and sphere tests
 struct RayCtx {
     v3 o, d;

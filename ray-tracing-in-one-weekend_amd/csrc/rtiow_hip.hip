@@ -138,7 +138,10 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // keyed by (pixel, sample), so the set of paths -- and every path's arithmetic -- is
 // independent of which lane ran it.
 #ifndef RT_LEAF_QUORUM
-#define RT_LEAF_QUORUM 16
+#define RT_LEAF_QUORUM 16         // trees in LDS (measured: 8 and 24 lose 0.3-0.8 % on the 485-sphere scenes)
+#endif
+#ifndef RT_LEAF_QUORUM_LARGE
+#define RT_LEAF_QUORUM_LARGE 8    // trees in device memory: a waiting leaf holds its lane up for longer walks (10^6 spheres: +2.8 % over 16)
 #endif
 // Shapes of the kernel.  When nodes, spheres and full-depth stacks fit in LDS every traversal
 // step reads LDS; the block is 1024 threads (4 waves per SIMD, measured 4-5 % faster than 3)
@@ -221,6 +224,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
         __syncthreads();
     }
 
+double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
+    asm volatile("" : "+v"(rcp_nx), "+v"(rcp_ny));   // (kept in registers, not recomputed where they are used)
     // a tile is 8x8 or 4x4 pixels (tile_shift 3 or 2)
     const uint32_t tile_side = 1u << tile_shift, tile_px = tile_side * tile_side;
     const uint32_t tiles_x = (nx + tile_side - 1) >> tile_shift, tiles_y = (ny + tile_side - 1) >> tile_shift, n_tiles = tiles_x * tiles_y;
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                         // the reference's row index runs bottom-up (main.cpp:126)
                         const double ii = (double)x + g.canonical();   // dist{0, 1}: u * 1 + 0 = u
                         const double jj = (double)(ny - 1 - y) + g.canonical();
-                        const double u = ii / (double)nx, v = jj / (double)ny;
+// ii / nx and jj / ny (main.cpp:132-133), the denominators' part of the division done once per wave
+                        const double u = div_by_shared(ii, (double)nx, rcp_nx), v = div_by_shared(jj, (double)ny, rcp_ny);
                         r = camera_ray(*reinterpret_cast<const DCamera *>(lds_raw), u, v, g);
                         thr = mk(1, 1, 1);
                         depth = 0;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                 int prim;
                 ++nrays;
                 if (COSTING) work += 8;   // claiming, set-up and shading of one segment, in node-step units
-                if (world_closest_voted<RT_LEAF_QUORUM, LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats)) {
+                if (world_closest_voted<(LDS_TREE ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats)) {
                     lane_stats.add(3, (uint32_t)__popcll(__ballot(true)));
                     v3 p, nn, att;
                     Ray nextray;

@@ -144,3 +144,13 @@ def test_single_precision_node_test_is_conservative():
     r = subprocess.run([exe, "400000000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 violations" in r.stdout
+
+
+def test_division_by_a_shared_reciprocal_is_the_ieee_division():
+    # The render kernel forms u = (x + xi) / nx from the refined reciprocal of nx, computed once per wave.
+    # The checker compares that with the hardware's full IEEE division for every image size up to 8192
+    # (and a spread of larger ones), 65 536 numerators each.
+    exe = os.path.join(ROOT, "ray-tracing-in-one-weekend_amd", "csrc", "division_check")
+    r = subprocess.run([exe, "65536"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " mismatches 0" in r.stdout
