@@ -45,7 +45,7 @@ def decode_png(data):
     return rows[:, 1:].reshape(h, w, 3)
 
 
-@pytest.mark.parametrize("scene", ["mixed", "book2", "ties"])
+@pytest.mark.parametrize("scene", ["mixed", "book2", "ties", "lists"])
 def test_object_hit_one_ray_at_a_time(tmp_path, scene):
     g = golden("trace_" + scene)
     rays, exp = g["rays"][-300:], g["expected"][-300:]
