@@ -121,6 +121,7 @@ struct DScene {
     uint32_t n_items;
     uint32_t stack_depth;     // entries per lane
     uint32_t recheck_all;     // test switch: treat every postponed box test as failed (see world_closest_voted)
+    uint32_t wide_radiance;   // some albedo or texture colour lies outside [0, 1]: a sample's radiance may leave [0, 1]
     FarSlack far;
     // How far a moving sphere can be from the box the reference gives it (moving_sphere.cpp:51-60
     // covers the start position only, and shutter times reach outside [time0, time1]: camera.cpp:41).

@@ -122,6 +122,29 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
     used[i] = g.over ? -1 : g.pos;
 }
 
+// Adds one sample's radiance to a pixel's three sums in LDS.  The sums are integers in units of 2^-50:
+// for |x| < 2, x 2^50 + 1.5 2^52 has its unit in the last place, so its bit pattern minus that of
+// 1.5 2^52 is x 2^50 rounded to the nearest integer (one fma and one subtraction).  Sums of integers
+// do not depend on the order of the additions.  A launch may add 4096 samples to a pixel.
+// `wide`: the scene has an albedo or texture colour outside [0, 1], so that a sample's radiance is not
+// bounded by the sky's 1; its sums are doubles, added in the order the wave reaches them.
+__device__ __forceinline__ long long radiance_units(double x) {
+    // (the low word of 1.5 2^52 is zero: the subtraction touches the high word only)
+    const double v = __builtin_fma(x, 0x1p50, 0x1.8p52);
+    return (long long)(((unsigned long long)((uint32_t)__double2hiint(v) - 0x43380000u) << 32) | (uint32_t)__double2loint(v));
+}
+__device__ __forceinline__ void add_radiance(long long *q, double cx, double cy, double cz, uint32_t stride, bool wide) {
+    if (wide) {
+        __hip_atomic_fetch_add(reinterpret_cast<double *>(q), cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(reinterpret_cast<double *>(q + stride), cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(reinterpret_cast<double *>(q + 2u * stride), cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    __hip_atomic_fetch_add(q, radiance_units(cx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q + stride, radiance_units(cy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q + 2u * stride, radiance_units(cz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // The pixel/sample loop (main.cpp:126-141) with ray_colour (main.cpp:30-50) unrolled
 // into one loop over ray segments.
 //
@@ -152,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_batch(DCamera cam, const doub
 // entries spill to it.
 constexpr int kWavesMax = 4, kWavesMin = 3;   // waves per SIMD
 constexpr size_t kCameraLds = 192;            // the block's copy of the camera
-constexpr size_t kHeadLds = kCameraLds + 48;  // ... followed by the scene's FarSlack and reach
+constexpr size_t kHeadLds = kCameraLds + 64 + 16 * 16;  // ... followed by the scene's FarSlack and reach, 1/nx and 1/ny, and each wave's four open tiles
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 #ifdef RT_LANE_STATS
 constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics slots per wave of up to 1024 blocks
@@ -160,6 +183,7 @@ constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics 
 constexpr size_t kCounters = 4;                         // rays, tile queue, and the same for the costing pass
 #endif
 constexpr uint32_t kOrderMinSamples = 32;               // frames at least this deep get their tiles ordered by cost
+constexpr uint32_t kSamplesPerLaunch = 4096;            // samples a launch may add to a pixel's 64-bit sums (2^51 units each at most)
 
 // COSTING: the pass that ranks the tiles -- the same walk over a few samples, but instead of
 // adding to the image each tile records how much work it was (tile_cost).
@@ -170,11 +194,12 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
                                                        uint32_t n_lleaves, uint32_t stack_cap, int *spill,
-                                                       const uint32_t *tile_order, uint32_t *tile_cost, uint32_t tile_shift) {
+                                                       const uint32_t *tile_order, uint32_t *tile_cost, uint32_t tile_shift,
+                                                       uint32_t sums_per_wave) {
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // LDS: [camera][far slack][tile sums: waves x 64 px x rgb doubles][stacks: stack_cap x block ints][nodes][leaves]
+    // LDS: [camera][far slack][tile sums: waves x sums_per_wave bytes][stacks: stack_cap x block ints][nodes][leaves]
     // The camera's 24 doubles are needed once per path; as kernel arguments they would sit in 48
     // scalar registers for the whole kernel and push other scalars out into vector-register lanes,
     // to be fetched back with vector instructions in the middle of the hot loops.
@@ -184,8 +209,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
     static_assert(offsetof(DScene, reach_a) == offsetof(DScene, far) + 20 && offsetof(DScene, reach_b) == offsetof(DScene, far) + 32 && kHeadLds - kCameraLds >= 44,
                   "far slack and reach are copied together");
     if (tid < 11) reinterpret_cast<float *>(lds_raw + kCameraLds)[tid] = reinterpret_cast<const float *>(&sc.far)[tid];
-    double *tile_sum = reinterpret_cast<double *>(lds_raw + kHeadLds) + wave * 192;
-    char *const stacks = lds_raw + kHeadLds + kRenderWaves * 192 * sizeof(double);
+    long long *const sums = reinterpret_cast<long long *>(lds_raw + kHeadLds + (size_t)wave * sums_per_wave);
+    char *const stacks = lds_raw + kHeadLds + (size_t)kRenderWaves * sums_per_wave;
     char *ltree = stacks + (size_t)stack_cap * kRenderBlock * sizeof(int);
     const LaneStack st = {reinterpret_cast<int *>(stacks) + tid, kRenderBlock, (int)stack_cap,
                           spill ? spill + (size_t)blockIdx.x * kRenderBlock + tid : nullptr, (int)(gridDim.x * kRenderBlock)};
@@ -224,8 +249,11 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
         __syncthreads();
     }
 
-double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
-    asm volatile("" : "+v"(rcp_nx), "+v"(rcp_ny));   // (kept in registers, not recomputed where they are used)
+    // the denominators' part of the divisions ii / nx and jj / ny (see div_by_shared), read back where a path is claimed
+    double *const rcp_size = reinterpret_cast<double *>(lds_raw + kCameraLds + 48);
+    if (tid == 0) { rcp_size[0] = refined_rcp((double)nx); rcp_size[1] = refined_rcp((double)ny); }
+    uint32_t *const ring_tile = reinterpret_cast<uint32_t *>(lds_raw + kCameraLds + 64) + wave * 4;   // the tile in each of this wave's ring entries
+    __syncthreads();
     // a tile is 8x8 or 4x4 pixels (tile_shift 3 or 2)
     const uint32_t tile_side = 1u << tile_shift, tile_px = tile_side * tile_side;
     const uint32_t tiles_x = (nx + tile_side - 1) >> tile_shift, tiles_y = (ny + tile_side - 1) >> tile_shift, n_tiles = tiles_x * tiles_y;
@@ -235,27 +263,91 @@ double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
     if (!COSTING) lane_stats.c = counters + 4 + 12 * (blockIdx.x * 16 + wave);   // zeroed by rt_render
 #endif
 
-    for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) {
-            tile = (uint32_t)atomicAdd(counters + 1, 1ull);
-            if (tile < n_tiles && tile_order) tile = tile_order[tile];
+    // A wave keeps up to `ring` tiles open at a time: one whose paths it is still claiming, the others
+    // draining.  Lanes whose path has ended never wait for the last long paths of a tile: when the tile
+    // in hand has no unclaimed path left the wave opens the next one beside it.  A tile's sums are kept
+    // in LDS as 64-bit integers (radiance in units of 2^-50): integer sums do not depend on the order
+    // of the additions, so the image does not depend on which lane, wave or tile size carried a path,
+    // nor on how tiles overlapped.  Nothing is counted per round: whether an open tile is finished
+    // (no lane carries a path of it) is only asked when the wave needs its place in the ring.
+    const uint32_t total = tile_px * (s_end - s_begin);   // paths of a tile
+    // (a scene whose radiance is not bounded keeps sums of doubles: one tile at a time then, so that the
+    // order of the additions, and with it every bit of the image, is the same from run to run)
+    const bool wide = sc.wide_radiance != 0;
+    const uint32_t ring = (COSTING || wide) ? 1u : (sums_per_wave / (tile_px * 24u) < 4u ? sums_per_wave / (tile_px * 24u) : 4u);
+    for (uint32_t i = lane; i < sums_per_wave / 8u; i += 64u) sums[i] = 0;
+    uint32_t ring_used = 0;                 // bit e: entry e holds a tile that has not been written out
+    uint32_t cur = 0, next = total, cur_x = 0, cur_y = 0;   // the entry being claimed from and its first unclaimed path
+    bool queue_done = false;
+    uint32_t work = 0;   // per lane: traversal iterations and rounds it took part in (see world_closest_voted)
+
+    bool alive = false;
+    uint32_t slot = 0;   // pixel-in-tile of the lane's current path, and (from bit 6) the ring entry of its tile
+    Ray r = {mk(0, 0, 0), mk(0, 0, 1), 0};
+    v3 thr = mk(1, 1, 1);
+    uint32_t depth = 0;
+    StreamRng g = {1, 0, 0, 0};
+
+    // a finished tile: its sums go to the image (or, in the costing pass, its cost to the cost table)
+    auto flush = [&](uint32_t e, uint32_t tile) {
+        if (COSTING) {
+            // the tile's cost is the work its busiest lane counted (a count, not a duration: durations
+            // depend on what else the CU is running)
+            uint32_t segs = work;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(segs, off); segs = o > segs ? o : segs; }
+            if (lane == 0) tile_cost[tile] = segs;
+            work = 0;
+            return;
         }
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= n_tiles) break;
-        uint32_t work = 0;   // per lane: traversal iterations and rounds it took part in (see world_closest_voted)
-        const uint32_t tile_x = (tile % tiles_x) << tile_shift, tile_y = (tile / tiles_x) << tile_shift;
-        const uint32_t total = tile_px * (s_end - s_begin);
-        uint32_t next = 0;   // wave-uniform: first unclaimed path of the tile
-        tile_sum[lane] = 0; tile_sum[64 + lane] = 0; tile_sum[128 + lane] = 0;
+        const uint32_t x = ((tile % tiles_x) << tile_shift) + (lane & (tile_side - 1u)), y = ((tile / tiles_x) << tile_shift) + (lane >> tile_shift);
+        if (lane < tile_px) {
+            long long *q = sums + (size_t)e * 3u * tile_px + lane;
+            if (x < nx && y < ny) {
+                AccT *a = accum + ((size_t)y * nx + x) * 3;
+                auto value = [wide](long long v) { return wide ? __longlong_as_double(v) : (double)v * 0x1p-50; };
+                a[0] += (AccT)value(q[0]); a[1] += (AccT)value(q[tile_px]); a[2] += (AccT)value(q[2u * tile_px]);
+            }
+            q[0] = 0; q[tile_px] = 0; q[2u * tile_px] = 0;
+        }
+    };
+    // writes out every open tile that no lane works for any more (the tile in hand must be used up)
+    auto retire = [&]() {
+#pragma unroll
+        for (uint32_t e = 0; e < 4u; ++e) {
+            if (!(ring_used & (1u << e))) continue;
+            if (__ballot(alive && (slot >> 6) == e) != 0) continue;
+            flush(e, (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_tile[e]));
+            ring_used &= ~(1u << e);
+        }
+    };
 
-        bool alive = false;
-        uint32_t slot = 0;   // pixel-in-tile of the lane's current path
-        Ray r = {mk(0, 0, 0), mk(0, 0, 1), 0};
-        v3 thr = mk(1, 1, 1);
-        uint32_t depth = 0;
-        StreamRng g = {1, 0, 0, 0};
+    for (;;) {
+        // Tile management, outside the loop over rounds: the tile in hand is used up (or there is none
+        // yet) and some lane has nothing to do -- open the next tile, if the ring has room for it.
+        if (next >= total && !queue_done) {
+            if (ring_used == (1u << ring) - 1u) retire();
+            if (ring_used != (1u << ring) - 1u) {
+                uint32_t tile = 0;
+                if (lane == 0) {
+                    tile = (uint32_t)atomicAdd(counters + 1, 1ull);
+                    if (tile < n_tiles && tile_order) tile = tile_order[tile];
+                }
+                tile = __builtin_amdgcn_readfirstlane(tile);
+                if (tile >= n_tiles) {
+                    queue_done = true;
+                } else {
+                    cur = (uint32_t)__builtin_ctz(~ring_used);
+                    if (lane == 0) ring_tile[cur] = tile;
+                    ring_used |= 1u << cur;
+                    next = 0;
+                    cur_x = (tile % tiles_x) << tile_shift; cur_y = (tile / tiles_x) << tile_shift;
+                }
+            }
+        }
+        if (queue_done && next >= total && !__any(alive)) break;
 
+        // rounds: until the tile in hand runs out of paths while a lane is idle (and more tiles may come)
         for (;;) {
             // lanes without a path claim the next unclaimed ones, in lane order
             const unsigned long long want = __ballot(!alive);
@@ -265,9 +357,10 @@ double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
                 const uint32_t claimed = (uint32_t)__popcll(want);
                 next = (total - next > claimed) ? next + claimed : total;
                 if (!alive && k < total) {
-                    slot = k & (tile_px - 1u);
-                    const uint32_t x = tile_x + (slot & (tile_side - 1u)), y = tile_y + (slot >> tile_shift);
-                    if (x < nx && y < ny) {
+                    const uint32_t pix = k & (tile_px - 1u);
+                    const uint32_t x = cur_x + (pix & (tile_side - 1u)), y = cur_y + (pix >> tile_shift);
+                    if (x < nx && y < ny) {   // (a ragged tile's pixels beyond the image have nothing to trace)
+                        slot = pix | (cur << 6);
                         const uint32_t smp = s_begin + (k >> (2u * tile_shift));
                         // (the seed passes through an opaque move: the ten pairs of round keys derived
                         // from it are then formed here by scalar additions, instead of being hoisted
@@ -278,8 +371,8 @@ double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
                         // the reference's row index runs bottom-up (main.cpp:126)
                         const double ii = (double)x + g.canonical();   // dist{0, 1}: u * 1 + 0 = u
                         const double jj = (double)(ny - 1 - y) + g.canonical();
-// ii / nx and jj / ny (main.cpp:132-133), the denominators' part of the division done once per wave
-                        const double u = div_by_shared(ii, (double)nx, rcp_nx), v = div_by_shared(jj, (double)ny, rcp_ny);
+                        // ii / nx and jj / ny (main.cpp:132-133), the denominators' part of the division done once per wave
+                        const double u = div_by_shared(ii, (double)nx, rcp_size[0]), v = div_by_shared(jj, (double)ny, rcp_size[1]);
                         r = camera_ray(*reinterpret_cast<const DCamera *>(lds_raw), u, v, g);
                         thr = mk(1, 1, 1);
                         depth = 0;
@@ -287,10 +380,7 @@ double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
                     }
                 }
             }
-            if (!__any(alive)) {
-                if (next >= total) break;
-                continue;
-            }
+            if (!__any(alive)) break;   // nothing to trace: more tiles, or the end
             lane_stats.add(2, (uint32_t)__popcll(__ballot(alive)));
             if (want != 0) lane_stats.add(5, (uint32_t)__popcll(want));
             if (alive) {
@@ -317,28 +407,17 @@ double rcp_nx = refined_rcp((double)nx), rcp_ny = refined_rcp((double)ny);
                 } else {
                     lane_stats.add(4, (uint32_t)__popcll(__ballot(true)));
                     const v3 c = sky(r.d);
-                    __hip_atomic_fetch_add(tile_sum + slot, c.x * thr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(tile_sum + 64 + slot, c.y * thr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(tile_sum + 128 + slot, c.z * thr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!COSTING) {
+                        long long *q = sums + (slot >> 6) * 3u * tile_px + (slot & 63u);
+                        add_radiance(q, c.x * thr.x, c.y * thr.y, c.z * thr.z, tile_px, wide);
+                    }
                     alive = false;
                 }
             }
-        }
-        if (COSTING) {
-            // costing pass: the image is not touched; the tile's cost is the work its busiest lane
-            // counted (a count, not a duration: durations depend on what else the CU is running)
-            uint32_t segs = work;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(segs, off); segs = o > segs ? o : segs; }
-            if (lane == 0) tile_cost[tile] = segs;
-            continue;
-        }
-        const uint32_t x = tile_x + (lane & (tile_side - 1u)), y = tile_y + (lane >> tile_shift);
-        if (lane < tile_px && x < nx && y < ny) {
-            AccT *a = accum + ((size_t)y * nx + x) * 3;
-            a[0] += (AccT)tile_sum[lane]; a[1] += (AccT)tile_sum[64 + lane]; a[2] += (AccT)tile_sum[128 + lane];
+            if (next >= total && !queue_done && !__all(alive)) break;   // a lane is idle and the tile in hand has nothing for it
         }
     }
+    retire();   // (no lane is alive: every tile still open is written out)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
     if (lane == 0) atomicAdd(counters, nrays);
@@ -501,6 +580,7 @@ struct rt_scene {
     int render_waves = kWavesMin;            // per SIMD
     uint32_t render_lnodes = 0, render_lleaves = 0, render_stack_cap = 0;
     size_t render_lds_bytes = 0;
+    uint32_t render_sums_per_wave = 0;        // bytes of LDS each wave has for the sums of its open tiles
     uint32_t n_nodes_dev = 0, n_prims_dev = 0;
     int n_cus = 256;
 };
@@ -1075,7 +1155,10 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     const uint32_t stack_depth = fl.max_depth + 2;
     size_t spill_ints = 0;
     {
-        const size_t sums = 192 * sizeof(double);   // per wave
+        // per wave: the sums of its open tiles, 24 bytes a pixel -- four 4x4 tiles or one 8x8 tile beside a
+        // tree that fills LDS, twice that when only the top of the tree is there
+        constexpr size_t kSumsLdsTree = 1536, kSumsLargeTree = 3072;
+        size_t sums = kSumsLdsTree;
         auto whole_tree = [&](int waves) {
             return kHeadLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
                    fl.leaf_boxes.size() * (static_scene ? SLEAF_STRIDE : LLEAF_STRIDE);
@@ -1095,6 +1178,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             s->render_stack_cap = stack_depth;
             s->render_lds_bytes = whole;
         } else {
+            sums = kSumsLargeTree;
             uint32_t cap = std::min<uint32_t>(stack_depth, kSpillStackCap);
             if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(1, atoi(force_cap)));
             s->render_waves = kWavesMax;
@@ -1107,6 +1191,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             s->render_lds_bytes = base + ((k * LNODE_STRIDE + 7) & ~(size_t)7);
             spill_ints = (size_t)(stack_depth - cap) * s->n_cus * 256 * kWavesMax;
         }
+        s->render_sums_per_wave = (uint32_t)sums;
     }
     lap("kernel shape, top levels staged");
     s->n_prims_desc = desc->n_prims;
@@ -1185,6 +1270,14 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = stack_depth;
+    // can a sample's radiance leave [0, 1]?  (the sky's never does; attenuations are texture colours and metal albedos)
+    s->d.wide_radiance = 0;
+    for (uint32_t i = 0; i < desc->n_textures; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (desc->textures[i].kind == RT_TEX_CONSTANT && !(desc->textures[i].colour[k] >= 0 && desc->textures[i].colour[k] <= 1)) s->d.wide_radiance = 1;
+    for (uint32_t i = 0; i < desc->n_materials; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (desc->materials[i].kind == RT_MAT_METAL && !(desc->materials[i].albedo[k] >= 0 && desc->materials[i].albedo[k] <= 1)) s->d.wide_radiance = 1;
     // RTIOW_RECHECK_ALL_LEAVES makes every hit of the static-scene variant take its second, exact
     // walk (tests).
     {
@@ -1439,8 +1532,9 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     }
 #define RT_LAUNCH(T, L, W, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
     hipLaunchKernelGGL((k_render<T, L, W, C, D>), grid, block, scene->render_lds_bytes, stream, dsc, cam, pr->nx, pr->ny,   \
-                       pr->sample_begin, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                 \
-                       scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT)
+                       s_from, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                           \
+                       scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT, \
+                       scene->render_sums_per_wave)
 #define RT_LAUNCH_TREE(T, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                      \
     do {                                                                                                                  \
         if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \
@@ -1452,6 +1546,7 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
         if (scene->render_defer) RT_LAUNCH_TREE(T, C, true, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                             \
         else RT_LAUNCH_TREE(T, C, false, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                                              \
     } while (0)
+    uint32_t s_from = pr->sample_begin;
     const uint32_t *order = nullptr;
     if (f.ordered) {
         const uint32_t cost_tiles_x = (pr->nx + 7) / 8, n_cost = cost_tiles_x * ((pr->ny + 7) / 8);
@@ -1464,8 +1559,13 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
         }
         order = sorted;
     }
-    if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, pr->sample_end, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
-    else RT_LAUNCH_SHAPE(double, false, pr->sample_end, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
+    // (a launch adds at most kSamplesPerLaunch samples to a pixel's integer sums; deeper frames take several)
+    for (; s_from < pr->sample_end; s_from += kSamplesPerLaunch) {
+        const uint32_t s_to = pr->sample_end - s_from > kSamplesPerLaunch ? s_from + kSamplesPerLaunch : pr->sample_end;
+        if (s_from != pr->sample_begin) HIP_TRY(hipMemsetAsync(mem.counters + 1, 0, sizeof(unsigned long long), stream));   // the tile queue starts over
+        if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, s_to, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
+        else RT_LAUNCH_SHAPE(double, false, s_to, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
+    }
 #undef RT_LAUNCH_SHAPE
 #undef RT_LAUNCH_TREE
 #undef RT_LAUNCH
