@@ -1498,11 +1498,9 @@ static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) 
     // 8x8-pixel tiles fill the 64 lanes with a single sample per pixel; from 4 samples per pixel a
     // 4x4 tile does, and tiles a quarter the size leave a quarter of the imbalance at the end of
     // the frame (measured faster from 8 to 1024 samples, within 2 % at 32).
-    // Trees that do not fit in LDS (walks three times as long, costs spread evenly over the image) keep
-    // 8x8 tiles below 64 samples: a tile's pool of paths drains at its end, which few paths per tile
-    // feel more than the coarser balance (10^6 spheres: 11.1 against 13.7 ms at 8 spp, 30.1 against
-    // 33.4 ms at 32, even at 64, 217 against 206 ms at 256).
-    f.tile_shift = (spp >= 4 && (scene->render_lds_tree || spp >= 64)) ? 2u : 3u;
+    // (with several tiles open per wave no lane waits at a tile's end, and the small tiles win at every
+    // depth from 4 samples on: 10^6 spheres at 8 spp 8.1 against 9.0 ms, the 485 spheres 3.3 against 4.8)
+    f.tile_shift = spp >= 4 ? 2u : 3u;
     if (const char *e = getenv("RTIOW_TILE_SHIFT")) f.tile_shift = std::min(3u, std::max(1u, (uint32_t)atoi(e)));   // 1: 2x2 ... 3: 8x8 (experiments)
     const uint32_t tile_side = 1u << f.tile_shift;
     f.tiles_x = (pr->nx + tile_side - 1) >> f.tile_shift;
