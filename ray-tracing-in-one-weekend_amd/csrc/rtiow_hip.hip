@@ -1558,7 +1558,8 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
         order = sorted;
     }
     // (a launch adds at most kSamplesPerLaunch samples to a pixel's integer sums; deeper frames take several)
-    for (; s_from < pr->sample_end; s_from += kSamplesPerLaunch) {
+    for (uint64_t from = pr->sample_begin; from < pr->sample_end; from += kSamplesPerLaunch) {
+        s_from = (uint32_t)from;
         const uint32_t s_to = pr->sample_end - s_from > kSamplesPerLaunch ? s_from + kSamplesPerLaunch : pr->sample_end;
         if (s_from != pr->sample_begin) HIP_TRY(hipMemsetAsync(mem.counters + 1, 0, sizeof(unsigned long long), stream));   // the tile queue starts over
         if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, s_to, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
