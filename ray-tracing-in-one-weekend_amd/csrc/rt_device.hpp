@@ -385,23 +385,28 @@ __device__ __forceinline__ v3 prim_centre(const DPrim *p, uint32_t moving, doubl
 // sphere.cpp:9-45, moving_sphere.cpp:13-49: the root the reference accepts in
 // (tmin, tmax), nearer root first
 // (radius2 = radius * radius, as sphere.cpp:16 forms it)
-__device__ __forceinline__ bool sphere_root(v3 c, double radius2, const RayCtx &r, double tmin, double tmax, double &t_out) {
+// (in two halves: the discriminant, and the roots of a positive one)
+__device__ __forceinline__ void sphere_disc(v3 c, double radius2, const RayCtx &r, double &b, double &disc) {
     v3 oc = vsub(r.o, c);
-    double b = vdot(oc, r.d);
+    b = vdot(oc, r.d);
     double cc = vdot(oc, oc) - radius2;
-    double disc = b * b - r.a * cc;
-    bool hit = false;
-    if (disc > 0) {
-        double root = sqrt(disc);
-        double t = (-b - root) / r.a;
+    disc = b * b - r.a * cc;
+}
+__device__ __forceinline__ bool sphere_roots(double b, double disc, const RayCtx &r, double tmin, double tmax, double &t_out) {
+    double root = sqrt(disc);
+    double t = (-b - root) / r.a;
+    bool hit = t < tmax && t > tmin;
+    if (!hit) {   // the farther root only when the nearer one is not accepted (sphere.cpp:31)
+        t = (-b + root) / r.a;
         hit = t < tmax && t > tmin;
-        if (!hit) {   // the farther root only when the nearer one is not accepted (sphere.cpp:31)
-            t = (-b + root) / r.a;
-            hit = t < tmax && t > tmin;
-        }
-        t_out = t;
     }
+    t_out = t;
     return hit;
+}
+__device__ __forceinline__ bool sphere_root(v3 c, double radius2, const RayCtx &r, double tmin, double tmax, double &t_out) {
+    double b, disc;
+    sphere_disc(c, radius2, r, b, disc);
+    return disc > 0 && sphere_roots(b, disc, r, tmin, tmax, t_out);
 }
 
 // Lane-utilisation counters of the render kernel, compiled in with -DRT_LANE_STATS (the
@@ -612,8 +617,8 @@ __device__ __forceinline__ void leaf_candidate(const DPrim *prims, int32_t prim,
     if (sphere_root(prim_centre(p, moving, r.time), p->r * p->r, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
 }
 
-__device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim, bool moving, const RayCtx &r,
-                                                   double tmin, double tmax, Trav &tv) {
+// the discriminant of the sphere in an LDS leaf record (centre at the ray's time: moving_sphere.cpp:3-5)
+__device__ __forceinline__ void leaf_disc_lds(const char *rec, bool moving, const RayCtx &r, double &b, double &disc) {
     const double *p = reinterpret_cast<const double *>(rec);
     v3 c = mk(p[0], p[1], p[2]);
     const double radius2 = p[3];   // the LDS copy holds the square
@@ -622,8 +627,7 @@ __device__ __forceinline__ void leaf_candidate_lds(const char *rec, int32_t prim
         const double s = (kind == PK_MOVING_UNIT) ? r.time : (r.time - p[7]) / (p[8] - p[7]);
         c = vadd(c, vmul(mk(p[4], p[5], p[6]), s));
     }
-    double t;
-    if (sphere_root(c, radius2, r, tmin, tmax, t)) take_if_closer(t, prim, tv);
+    sphere_disc(c, radius2, r, b, disc);
 }
 
 // One leaf.  First the reference's own test of the leaf's box (aabb.cpp:8-57, in double, with the
@@ -665,8 +669,20 @@ __device__ __forceinline__ void leaf_step_lds(const char *lleaves, const RayCtx 
             reached = box_test_ordered(rec, r, tmin, tmax, entry);
         }
         if (reached) {
-            leaf_candidate_lds(rec + 48, 2 * leaf, ref & LEAF_MOVING0, r, tmin, tmax, tv);
-            if (ref & LEAF_TWO) leaf_candidate_lds(rec + 48 + LPRIM_BYTES, 2 * leaf + 1, ref & LEAF_MOVING1, r, tmin, tmax, tv);
+            // Both discriminants first, then the roots -- square root and division, the dear part --
+            // in ONE pass for whichever sphere of the lane's leaf has a positive one: run sphere by
+            // sphere, each pass would execute for the few lanes that need it.  A lane whose ray meets
+            // the lines of both spheres takes a second pass.  (The order of the two candidates does not
+            // matter: the nearer wins, the later primitive among equals.)
+            double b0, d0, b1 = 0, d1 = -1;
+            leaf_disc_lds(rec + 48, ref & LEAF_MOVING0, r, b0, d0);
+            if (ref & LEAF_TWO) leaf_disc_lds(rec + 48 + LPRIM_BYTES, ref & LEAF_MOVING1, r, b1, d1);
+            bool first = d0 > 0, second = d1 > 0;
+            while (first || second) {
+                double t;
+                if (sphere_roots(first ? b0 : b1, first ? d0 : d1, r, tmin, tmax, t)) take_if_closer(t, 2 * leaf + (first ? 0 : 1), tv);
+                if (first) first = false; else second = false;
+            }
         }
     }
     tv.cur = trav_pop<SPILL>(tv, st);
