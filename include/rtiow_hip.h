@@ -146,7 +146,13 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
  * first); its two small device buffers are allocated on the first such call for an image
  * size, which may synchronise the device.  A frame of the same camera, size and depth limit
  * as the scene's last costed frame reuses that frame's tile order and skips the pass.  The
- * image does not depend on any of this. */
+ * image does not depend on any of this: a pixel's samples are summed as 64-bit integers in
+ * units of 2^-50 (exact and order-independent; one rounding, when the sum is added to accum),
+ * so tile sizes, kernel shapes and schedules all give the same bits.  Calls deeper than 4096
+ * samples per pixel are split into several launches.  A scene with an albedo or texture
+ * colour outside [0, 1] -- radiance then has no bound -- is summed in doubles instead, in an
+ * order that is fixed for a given GPU.  A sample whose radiance is not finite leaves its
+ * pixel's sum undefined (as main.cpp:26-28 is for such a pixel). */
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 
