@@ -32,7 +32,7 @@ namespace rtd {
 struct __attribute__((aligned(16))) DNode {
     float bx[2][6];    // per child: min x, max x, min y, max y, min z, max z (plane_down / plane_up)
     int32_t child[2];  // >= 0 node index, < 0 leaf reference (see leaf_ref)
-    uint32_t flags;    // NF_SAFE0 | NF_SAFE1
+    uint32_t flags;    // NF_SAFE0 | NF_SAFE1 (a description of the subtrees; the walks decide by the leaf references' own bits)
     uint32_t pad;
 };
 static_assert(sizeof(DNode) == 64, "DNode is one 64-byte line");

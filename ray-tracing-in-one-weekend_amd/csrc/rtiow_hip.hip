@@ -156,10 +156,12 @@ __device__ __forceinline__ void add_radiance(long long *q, double cx, double cy,
 // A wave owns its tile's pixels x (s_end - s_begin) paths, numbered k = sample * pixels +
 // pixel-in-tile; a lane whose path has ended claims the next unclaimed k (lanes that
 // claim together take consecutive numbers), so every lane stays busy until the tile's
-// paths run out, whatever the mix of short sky paths and long glass paths in the tile.
-// A finished path adds its radiance to the tile's sums in LDS; the random stream is
-// keyed by (pixel, sample), so the set of paths -- and every path's arithmetic -- is
-// independent of which lane ran it.
+// paths run out, whatever the mix of short sky paths and long glass paths in the tile --
+// and then the wave opens its next tile beside the one that is still draining (see the
+// ring in the kernel).  A finished path adds its radiance to its tile's sums in LDS; the
+// random stream is keyed by (pixel, sample), so the set of paths -- and every path's
+// arithmetic -- is independent of which lane ran it, and the sums, being integers, of the
+// order in which they were added.
 #ifndef RT_LEAF_QUORUM
 #define RT_LEAF_QUORUM 16         // trees in LDS (measured: 8 and 24 lose 0.3-0.8 % on the 485-sphere scenes)
 #endif
