@@ -110,7 +110,15 @@ def _random_recipe(rng, path, moving=True):
         else:
             n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 17, 40, 150]))
             lines.append(f"bvh_begin {int(rng.integers(1, 1000))} 0 1")
-            lines += [sphere() for _ in range(n)]
+            k = 0
+            while k < n:
+                if rng.random() < 0.15:     # an object_list as one object of the bvh_node (1 to 5 members)
+                    members = int(rng.integers(1, 6))
+                    lines += ["list_begin"] + [sphere() for _ in range(members)] + ["list_end"]
+                    k += members
+                else:
+                    lines.append(sphere())
+                    k += 1
             lines.append("bvh_end")
     path.write_text("\n".join(lines) + "\n")
     return scale
