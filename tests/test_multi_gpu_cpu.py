@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT, golden, recipe
 
 
-def _worker(rank, world, port, spp, out_path):
+def _worker(rank, world, port, spp, out_path, total_spp=None):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -22,7 +22,7 @@ def _worker(rank, world, port, spp, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cam15 = np.load(os.path.join(ROOT, "tests", "golden", "frames.npz"))["camera"]
-    s0, s1 = bench.sample_range(rank, spp)
+    s0, s1 = bench.sample_range(rank, spp, world, total_spp)
     sums, _ = oracle_lib.Scene(os.path.join(ROOT, "tests", "golden", "scenes", "mixed.recipe")).render(
         cam15, 32, 16, s0, s1, 99, oracle_lib.ORC_RNG_STREAM)
     accum = torch.from_numpy(sums.astype(np.float32))
@@ -42,6 +42,17 @@ def test_sample_ranges_partition():
         assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
 
 
+def test_strong_scaling_ranges_partition_the_frame():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 3, 4, 8):
+        for total in (4096, 1024, 10, 7):
+            r = [bench.sample_range(k, None, world, total) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+
+
 def test_two_ranks_sum_to_one_rank(orc, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "sum.npy")
@@ -51,3 +62,14 @@ def test_two_ranks_sum_to_one_rank(orc, tmp_path):
     whole, _ = orc.Scene(recipe("mixed")).render(golden("frames")["camera"], 32, 16, 0, 6, 99, orc.ORC_RNG_STREAM)
     np.testing.assert_allclose(got, whole.astype(np.float32), rtol=2e-6, atol=1e-6)
     assert got.max() > 0
+
+
+def test_two_ranks_split_one_frames_samples(orc, tmp_path):
+    # strong scaling: the frame's 7 samples split 3 + 4 over two ranks ([g*S/G, (g+1)*S/G))
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sum.npy")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, None, out, 7), nprocs=2, join=True)
+    got = np.load(out)
+    whole, _ = orc.Scene(recipe("mixed")).render(golden("frames")["camera"], 32, 16, 0, 7, 99, orc.ORC_RNG_STREAM)
+    np.testing.assert_allclose(got, whole.astype(np.float32), rtol=2e-6, atol=1e-6)

@@ -86,17 +86,6 @@ def test_two_ranks_on_one_gpu_sum_to_one_rank(rt, tmp_path):
     assert abs(line["mean_radiance"] - whole.mean() / 8) < 1e-6
 
 
-def test_strong_scaling_ranges_partition_the_frame():
-    sys.path.insert(0, ROOT)
-    import bench
-    for world in (1, 2, 3, 4, 8):
-        for total in (4096, 1024, 10, 7):
-            r = [bench.sample_range(k, None, world, total) for k in range(world)]
-            assert r[0][0] == 0 and r[-1][1] == total
-            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
-            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
-
-
 def test_4k_frame_properties(rt):
     # BASELINE.json configs[3] is 3840x2160: no oracle renders that in seconds, so the checks are the
     # size-independent ones -- additivity over the sample ranges two GPUs would take, determinism,
