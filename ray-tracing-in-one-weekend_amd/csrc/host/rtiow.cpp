@@ -451,7 +451,7 @@ size_t nodes_over(size_t n, std::map<size_t, size_t>& memo) {
     return c;
 }
 constexpr size_t kParallelBuildMin = size_t(1) << 14;   // objects under a node worth a thread of its own
-int const kParallelBuildDepth = getenv("RTIOW_BUILD_DEPTH") ? atoi(getenv("RTIOW_BUILD_DEPTH")) : 4;                   // ... down to this depth: at most 16 threads
+constexpr int kParallelBuildDepth = 4;                   // ... down to this depth: at most 16 threads (RTIOW_BUILD_DEPTH=d overrides, 0 = serial)
 }  // namespace
 
 // The reference draws one axis per node from the shared generator, a node's own before its left
@@ -462,11 +462,14 @@ struct bvh_node::build_plan {
     std::vector<uint8_t> axis;            // by pre-order node number
     std::map<size_t, size_t> node_count;  // nodes_over, for the sizes that occur
     double t0, t1;
+    int parallel_depth;                   // halves of large nodes are built by threads of their own above this depth
 };
 
 bvh_node::build_plan bvh_node::draw_axes(std::mt19937& mt, size_t n, double t0, double t1) {
     build_plan plan;
     plan.t0 = t0; plan.t1 = t1;
+    char const* const depth_env = std::getenv("RTIOW_BUILD_DEPTH");
+    plan.parallel_depth = depth_env ? std::atoi(depth_env) : kParallelBuildDepth;
     size_t const nodes = nodes_over(n, plan.node_count);
     plan.axis.resize(nodes);
     for (uint8_t& a : plan.axis) a = (uint8_t)dist(mt);
@@ -519,7 +522,7 @@ bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object cons
         auto build = [&plan, depth](std::span<std::unique_ptr<object const>> part, size_t at) {
             return std::unique_ptr<bvh_node const>(new bvh_node(plan, part, at, depth + 1));
         };
-        if (objects.size() >= kParallelBuildMin && depth < kParallelBuildDepth) {
+        if (objects.size() >= kParallelBuildMin && depth < plan.parallel_depth) {
             // (an exception from either half -- the reference's string literal -- comes out of here
             // after both have ended)
             auto other = std::async(std::launch::async, build, objects.subspan(0, half), left_index);
