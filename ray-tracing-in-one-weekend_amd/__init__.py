@@ -140,6 +140,7 @@ def host():
         lib.rth_last_error.restype = ctypes.c_char_p
         lib.rth_generate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p]
         lib.rth_world_load.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.rth_recipe_copy.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         lib.rth_world_generate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.rth_world_tables.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.rth_world_free.argtypes = [ctypes.c_void_p]
@@ -165,6 +166,12 @@ def _check(rc, what):
 def generate(kind, seed, path, n=0):
     """Writes a scene recipe: two_perlin, book1, book2 or stress (n spheres)."""
     if host().rth_generate(kind.encode(), seed, n, path.encode()):
+        raise RtError(host().rth_last_error().decode())
+
+
+def recipe_copy(src, dst):
+    """Loads a recipe and saves it again in the writer's own formatting."""
+    if host().rth_recipe_copy(str(src).encode(), str(dst).encode()):
         raise RtError(host().rth_last_error().decode())
 
 

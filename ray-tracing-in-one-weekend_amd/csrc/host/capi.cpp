@@ -110,6 +110,11 @@ int rth_generate(const char* kind, uint32_t seed, int n, const char* path) {
     return guarded([&] { generate(kind, seed, n).save(path); });
 }
 
+// Reads a recipe and writes it out again (the writer's own formatting): what a saved scene must survive.
+int rth_recipe_copy(const char* from, const char* to) {
+    return guarded([&] { recipe::load(from).save(to); });
+}
+
 // The same as rth_generate + rth_world_load without the detour through a recipe file: the
 // generator's world is built through the scene API, flattened and uploaded to `device`.
 int rth_world_generate(const char* kind, uint32_t seed, int n, int device, rth_world** out) {

@@ -109,6 +109,23 @@ def test_recipe_errors_are_reported(rt, tmp_path):
         rt.generate("nope", 1, str(tmp_path / "x.recipe"))
 
 
+@pytest.mark.parametrize("scene", ["lists", "mixed", "book2"])
+def test_recipes_survive_a_round_trip_through_the_writer(rt, tmp_path, scene):
+    # list groups inside bvh groups, bare spheres between groups, moving spheres: the same world comes back
+    copy = tmp_path / "copy.recipe"
+    rt.recipe_copy(recipe(scene), copy)
+    a_nodes, a_items = rt.world_tables(recipe(scene))
+    b_nodes, b_items = rt.world_tables(str(copy))
+    assert np.array_equal(a_nodes, b_nodes) and np.array_equal(a_items, b_items)
+    again = tmp_path / "again.recipe"
+    rt.recipe_copy(copy, again)
+    assert copy.read_bytes() == again.read_bytes()          # the writer's output is a fixed point
+    with pytest.raises(rt.RtError, match="list_begin"):
+        bad = tmp_path / "bad.recipe"
+        bad.write_text("rtiow-recipe 1\ntexture constant 1 1 1\nmaterial lambertian 0\nlist_begin\nsphere 0 0 0 0 1\nlist_end\n")
+        rt.world_tables(str(bad))
+
+
 def test_generators_are_deterministic(rt, tmp_path):
     for kind in ["two_perlin", "book1", "book2"]:
         p = tmp_path / (kind + ".recipe")
