@@ -47,8 +47,8 @@ print("ok", float(alone.mean()))
 '''
 
 
-def _port():
-    return str(29600 + os.getpid() % 1500)
+def _port(k=0):
+    return str(29600 + 2 * (os.getpid() % 1500) + k)
 
 
 def test_rccl_beside_the_render_kernel_in_a_one_rank_group():
@@ -65,7 +65,7 @@ def test_two_ranks_on_one_gpu_sum_to_one_rank(rt, tmp_path):
     # frame one process renders with all 8 (the halves are rounded to float before they are added).
     out = str(tmp_path / "sum.npy")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", _port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--master-port", _port(1), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--scene", "book2", "--nx", "320", "--ny", "180", "--total-spp", "8", "--backend", "gloo", "--share-device",
            "--timed-only", "--dump-accum", out]
     r = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=600, cwd=ROOT)
