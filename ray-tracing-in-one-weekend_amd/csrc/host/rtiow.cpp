@@ -503,7 +503,37 @@ bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object cons
             vec3 const lo = b->min();
             order[i] = keyed{axis == 0 ? lo.x() : (axis == 1 ? lo.y() : lo.z()), o};
         }
-        std::ranges::sort(order, [](keyed const& l, keyed const& r) -> bool { return l.key < r.key; });
+        auto const less = [](keyed const& l, keyed const& r) -> bool { return l.key < r.key; };
+        // Near the root of a large tree a node has threads to spare (its sibling subtrees take the others).
+        // When no two keys are equal, every sorting algorithm must arrive at the same order, so slices sorted
+        // in parallel and merged give what std::ranges::sort gives; if the merged order shows a tie (or a
+        // NaN), the reference's own algorithm decides it, on the original sequence.
+        int const threads = depth < plan.parallel_depth ? (1 << (plan.parallel_depth - depth)) : 1;
+        bool sorted = false;
+        if (threads > 1 && order.size() >= (size_t(1) << 16)) {
+            std::vector<keyed> const original(order.begin(), order.end());
+            size_t const n = order.size();
+            auto bound = [&](int k) { return n * (size_t)k / (size_t)threads; };
+            {
+                std::vector<std::future<void>> jobs;
+                for (int k = 0; k < threads; ++k)
+                    jobs.push_back(std::async(std::launch::async, [&, k] { std::sort(order.begin() + (long)bound(k), order.begin() + (long)bound(k + 1), less); }));
+                for (auto& j : jobs) j.get();
+            }
+            for (int width = 1; width < threads; width *= 2) {
+                std::vector<std::future<void>> jobs;
+                for (int k = 0; k + width < threads; k += 2 * width)
+                    jobs.push_back(std::async(std::launch::async, [&, k, width] {
+                        std::inplace_merge(order.begin() + (long)bound(k), order.begin() + (long)bound(k + width),
+                                           order.begin() + (long)bound(std::min(k + 2 * width, threads)), less);
+                    }));
+                for (auto& j : jobs) j.get();
+            }
+            sorted = true;
+            for (size_t i = 0; i + 1 < n && sorted; ++i) sorted = order[i].key < order[i + 1].key;
+            if (!sorted) std::copy(original.begin(), original.end(), order.begin());
+        }
+        if (!sorted) std::ranges::sort(order, less);
         for (auto& o : objects) (void)o.release();   // every pointer is in `order` now
         for (size_t i = 0; i < order.size(); ++i) objects[i].reset(order[i].ptr);
     }
