@@ -180,7 +180,7 @@ constexpr size_t kCameraLds = 192;            // the block's copy of the camera
 constexpr size_t kHeadLds = kCameraLds + 64 + 16 * 16;  // ... followed by the scene's FarSlack and reach, 1/nx and 1/ny, and each wave's four open tiles
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 #ifdef RT_LANE_STATS
-constexpr size_t kCounters = 4 + 12 * 16 * 1024;        // + 12 lane-statistics slots per wave of up to 1024 blocks
+constexpr size_t kCounters = 4 + 16 * 16 * 1024;        // + 16 statistics slots (12 lane counts, 3 phase clocks) per wave of up to 1024 blocks
 #else
 constexpr size_t kCounters = 4;                         // rays, tile queue, and the same for the costing pass
 #endif
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
     unsigned long long nrays = 0;
     LaneStats lane_stats;
 #ifdef RT_LANE_STATS
-    if (!COSTING) lane_stats.c = counters + 4 + 12 * (blockIdx.x * 16 + wave);   // zeroed by rt_render
+    if (!COSTING) lane_stats.c = counters + 4 + 16 * (blockIdx.x * 16 + wave);   // zeroed by rt_render
 #endif
 
     // A wave keeps up to `ring` tiles open at a time: one whose paths it is still claiming, the others
@@ -351,6 +351,10 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
 
         // rounds: until the tile in hand runs out of paths while a lane is idle (and more tiles may come)
         for (;;) {
+#ifdef RT_LANE_STATS
+            const long long clk0 = clock64();
+            long long clk1 = clk0, clk2 = clk0;
+#endif
             // lanes without a path claim the next unclaimed ones, in lane order
             const unsigned long long want = __ballot(!alive);
             if (want != 0 && next < total) {
@@ -383,6 +387,9 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                 }
             }
             if (!__any(alive)) break;   // nothing to trace: more tiles, or the end
+#ifdef RT_LANE_STATS
+            clk1 = clock64();
+#endif
             lane_stats.add(2, (uint32_t)__popcll(__ballot(alive)));
             if (want != 0) lane_stats.add(5, (uint32_t)__popcll(want));
             if (alive) {
@@ -392,7 +399,11 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                 int prim;
                 ++nrays;
                 if (COSTING) work += 8;   // claiming, set-up and shading of one segment, in node-step units
-                if (world_closest_voted<(LDS_TREE ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats)) {
+                const bool hit_something = world_closest_voted<(LDS_TREE ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats);
+#ifdef RT_LANE_STATS
+                clk2 = clock64();
+#endif
+                if (hit_something) {
                     lane_stats.add(3, (uint32_t)__popcll(__ballot(true)));
                     v3 p, nn, att;
                     Ray nextray;
@@ -416,6 +427,12 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                     alive = false;
                 }
             }
+#ifdef RT_LANE_STATS
+            if (lane_stats.c && lane == 0) {   // clocks of this round: claiming, set-up and walk, shading
+                const long long clk3 = clock64();
+                lane_stats.c[12] += (unsigned long long)(clk1 - clk0); lane_stats.c[13] += (unsigned long long)(clk2 - clk1); lane_stats.c[14] += (unsigned long long)(clk3 - clk2);
+            }
+#endif
             if (next >= total && !queue_done && !__all(alive)) break;   // a lane is idle and the tile in hand has nothing for it
         }
     }
@@ -1621,8 +1638,15 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         std::vector<unsigned long long> all(kCounters);
         HIP_TRY(hipMemcpy(all.data(), scene->counter.p, kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long c[16] = {0};
-        for (size_t w = 0; w < (kCounters - 4) / 12; ++w)
-            for (int q = 0; q < 12; ++q) c[4 + q] += all[4 + 12 * w + q];
+        unsigned long long clk[3] = {0, 0, 0};
+        for (size_t w = 0; w < (kCounters - 4) / 16; ++w) {
+            for (int q = 0; q < 12; ++q) c[4 + q] += all[4 + 16 * w + q];
+            for (int q = 0; q < 3; ++q) clk[q] += all[4 + 16 * w + 12 + q];
+        }
+        {
+            const double sum = (double)(clk[0] + clk[1] + clk[2]);
+            fprintf(stderr, "clocks: claiming %.1f %%, set-up and walk %.1f %%, shading %.1f %% of the waves' round time\n", 100 * clk[0] / sum, 100 * clk[1] / sum, 100 * clk[2] / sum);
+        }
         const char *phase[6] = {"node step", "leaf step", "round", "hit shading", "sky", "claim"};
         for (int q = 0; q < 6; ++q)
             fprintf(stderr, "lanes: %-11s executed %llu times by a wave, %.1f of 64 lanes, %.2f lane-visits per segment\n", phase[q], c[4 + 2 * q],
