@@ -165,6 +165,9 @@ __device__ __forceinline__ void add_radiance(long long *q, double cx, double cy,
 #ifndef RT_LEAF_QUORUM
 #define RT_LEAF_QUORUM 16         // trees in LDS (measured: 8 and 24 lose 0.3-0.8 % on the 485-sphere scenes)
 #endif
+#ifndef RT_LEAF_QUORUM_PAIRS
+#define RT_LEAF_QUORUM_PAIRS 24   // ... whose leaves hold the reference's pairs (book-2: +0.6 % over 16)
+#endif
 #ifndef RT_LEAF_QUORUM_LARGE
 #define RT_LEAF_QUORUM_LARGE 8    // trees in device memory: a waiting leaf holds its lane up for longer walks (10^6 spheres: +2.8 % over 16)
 #endif
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                 int prim;
                 ++nrays;
                 if (COSTING) work += 8;   // claiming, set-up and shading of one segment, in node-step units
-                const bool hit_something = world_closest_voted<(LDS_TREE ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats);
+                const bool hit_something = world_closest_voted<(LDS_TREE ? (DEFER ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_PAIRS) : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats);
 #ifdef RT_LANE_STATS
                 clk2 = clock64();
 #endif
