@@ -1,33 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--total-spp S]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--spp S | --total-spp S]
 
-One step = one pass of the hot path over one frame's worth of samples.  Default (c2, weak
-scaling): every rank renders `--spp` samples of every pixel of the 1920x1080 random-spheres
-frame (BASELINE.json configs[1]), rank r taking the global sample indices [r*spp, (r+1)*spp),
-and the float accumulation buffers are summed with one RCCL all-reduce.  With `--total-spp S`
-(or `--config c4`: 3840x2160, S = 4096, BASELINE.json configs[3]) the frame's S samples are
-SPLIT across the ranks, rank g taking [g*S/G, (g+1)*S/G) -- strong scaling.  The per-(pixel,
-sample) random streams make the union of the ranks' paths the same set for any G.  The scene
-is uploaded once and stays resident in HBM; only kernels and the all-reduce are timed.  The first
-frame of a view (the warm-up) also runs the short costing pass that ranks the tiles; frames of the
-same view reuse that order (`first_frame_kernel_ms` beside `roofline.kernel_ms`).
+One step = one pass of the hot path over one frame's worth of samples: every rank renders its
+range of global sample indices of every pixel, then the float accumulation buffers are summed with
+one RCCL all-reduce.  The frame is BASELINE.json configs[1]: the 1920x1080 random-spheres frame
+at 1024 samples per pixel.  With one GPU it renders them all.  With N > 1 the frame's 1024 samples
+are SPLIT across the ranks, rank g taking [g*S/N, (g+1)*S/N) -- strong scaling, the split the
+reference's README proposes; the per-(pixel, sample) random streams make the union of the ranks'
+paths the same set for any N.  `--spp S` instead gives every rank S samples of its own (weak
+scaling, rank r taking [r*S, (r+1)*S)); `--total-spp S` / `--config c4` (3840x2160, S = 4096,
+BASELINE.json configs[3]) split other totals.  The scene is uploaded once and stays resident in
+HBM; only kernels and the all-reduce are timed.  The first frame of a view (the warm-up) also runs
+the short costing pass that ranks the tiles; frames of the same view reuse that order
+(`first_frame_kernel_ms` beside `roofline.kernel_ms`).
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself, as
+fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything in the
+parent has touched the GPU (launch_ranks); under torch.distributed.run it finds those variables
+set and is one of the ranks.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job Mpaths/s (1 path = 1 camera sample followed
 through all its bounces).
 
-`roofline` is the bound that binds this kernel: vector-ALU issue.  The tree lives in LDS and
-HBM is idle, so the kernel is priced in VALU lane-slots: a SIMD issues 16 lanes per cycle, the
-chip 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-slots/s, which is the 78.6 TFLOP/s
-FP64 peak at 2 flop per slot.  `achieved` = lane-slots the kernel occupied per launch (the
-SQ_THREAD_CYCLES_VALU counter of the PMC pass over this very configuration, kept in
-profiles/valu.json) x 2 / the kernel's launch duration measured live with HIP events, i.e.
-an FMA-equivalent rate: what the same slots would deliver if every instruction were an f64
-FMA.  `frac` = achieved / peak <= 1.  `lanes_active`, `valu_busy` and `occupancy` come from
-the same pass.  `algorithmic_hbm` keeps the figure that prices the REFERENCE's traversal
-(32 B per box test, ...) against HBM peak: reference-work-equivalents, which this kernel
-neither fetches nor executes -- it can exceed 1 and says nothing about the hardware.
+`roofline` prices the kernel against the bound that binds it, the f64 vector ALU (the tree lives
+in LDS and HBM is idle): `achieved` = ALGORITHMIC flops of one launch -- rays/path x (box tests/ray
+x 27 + sphere tests/ray x 30 + 60), the counts being those of the REFERENCE's both-children
+traversal measured by the oracle on the same scene and camera -- / the launch's duration measured
+live with HIP events; `frac` = achieved / 78.6 TFLOP/s.  Beside it, from the PMC pass over the
+same configuration (profiles/valu.json, keyed by configuration): `valu_slot_occupancy` (VALU
+lane-slots the kernel occupied x 2 / time / peak: what the same slots would deliver if every
+instruction were an f64 FMA), `lanes_active`, `valu_busy`, `occupancy`, `executed_f64_tflops`.
+`algorithmic_hbm` keeps the figure that prices the reference's traversal in bytes (32 B per box
+test, ...) against HBM peak: this kernel fetches none of them -- it can exceed 1.
 
 `cpu_baseline` times the compiled reference classes (oracle/_ref/ref_capture) -- or the C
 oracle when that binary is absent -- on one host core over a bounded sample of the frame.
@@ -172,61 +178,156 @@ def sample_range(rank, spp, world=1, total_spp=None):
     return rank * spp, (rank + 1) * spp
 
 
-def valu_roofline(config_key, kernel_s):
-    """The binding bound from the PMC pass kept in profiles/valu.json (collected by
-    tools/profile_round.sh on exactly `config_key`; None for any other configuration)."""
-    path = os.path.join(ROOT, "profiles", "valu.json")
+def _keyed(path, config_key):
+    """The record of `config_key` in a profiles/*.json file written by tools/roofline_inputs.py."""
     if not os.path.exists(path):
         return None
-    v = json.load(open(path))
-    if v.get("config_key") != config_key:
-        return None
-    slots = v["SQ_THREAD_CYCLES_VALU"]
-    achieved = 2.0 * slots / kernel_s / 1e12
+    return json.load(open(path)).get("configs", {}).get(config_key)
+
+
+def roofline(config_key, counts, launch_paths, my_spp, kernel_ms):
+    """The `roofline` object of one configuration: algorithmic flops of a launch / its measured
+    duration against the f64 vector peak, with the PMC figures of the same configuration beside it
+    when tools/profile_round.sh collected them (profiles/valu.json, profiles/traffic.json)."""
+    k_s = float(np.mean(kernel_ms)) / 1e3
+    flops_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 27 + (counts["sphere_tests_per_ray"] +
+                                                counts["moving_tests_per_ray"]) * 30 + 60)
+    bytes_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 32 + counts["sphere_tests_per_ray"] * 16 +
+                                                counts["moving_tests_per_ray"] * 40) + 12.0 / max(1, my_spp)
+    achieved = launch_paths * flops_per_path / k_s / 1e12
     out = {"bound": "valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-           "meaning": "VALU lane-slots occupied per launch (SQ_THREAD_CYCLES_VALU of the PMC pass over this configuration) x 2 flop / live kernel time: "
-                      "FMA-equivalent rate against the f64 vector peak at the nominal 2.4 GHz",
-           "lane_slots_per_launch": slots, "source": "profiles/valu.json <- " + v.get("source", "?")}
-    for k in ("lanes_active", "valu_busy", "occupancy", "valu_insts_per_launch", "f64_flops_per_launch", "pmc_kernel_ms"):
-        if k in v:
-            out[k] = v[k]
-    if "f64_flops_per_launch" in v:
-        out["executed_f64_tflops"] = v["f64_flops_per_launch"] / kernel_s / 1e12
+           "meaning": "algorithmic flops of one launch = paths x rays/path x (box tests/ray x 27 + sphere tests/ray x 30 + 60), counts of the "
+                      "reference's both-children traversal measured by the oracle on this scene and camera, / the launch's duration (HIP events), "
+                      "against the f64 vector peak 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz",
+           "algorithmic_flops_per_launch": launch_paths * flops_per_path, "algorithmic_flops_per_path": flops_per_path, "counts": counts,
+           "config_key": config_key, "kernel": "k_render (timed frames reuse the warm-up frame's tile order: one launch per frame)",
+           "kernel_ms": k_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms]}
+    v = _keyed(os.path.join(ROOT, "profiles", "valu.json"), config_key)
+    if v is None:
+        out["pmc"] = f"no PMC pass over '{config_key}' in profiles/valu.json"
+    else:
+        slots = v["SQ_THREAD_CYCLES_VALU"]
+        out["valu_slot_occupancy"] = 2.0 * slots / k_s / 1e12 / FP64_PEAK_TFLOPS
+        out["lane_slots_per_launch"] = slots
+        out["pmc"] = "profiles/valu.json <- " + v.get("source", "?")
+        for k in ("lanes_active", "valu_busy", "occupancy", "valu_insts_per_launch", "f64_flops_per_launch", "pmc_kernel_ms"):
+            if k in v:
+                out[k] = v[k]
+        if "f64_flops_per_launch" in v:
+            out["executed_f64_tflops"] = v["f64_flops_per_launch"] / k_s / 1e12
+    # HBM bytes of one launch from the PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE)
+    t = _keyed(os.path.join(ROOT, "profiles", "traffic.json"), config_key)
+    traffic = t["hbm_bytes_per_launch"] if t else None
+    alg_gbs = launch_paths * bytes_per_path / k_s / 1e9
+    out.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
+                "hbm_frac": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "algorithmic_hbm": {"what": "reference-traversal bytes (32 B per box test, 16 B per static-sphere test, 40 B per moving-sphere test, 12 B of "
+                                            "framebuffer per pixel) / kernel time against HBM peak; the kernel fetches none of them when the tree is in LDS",
+                                    "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_launch": launch_paths * bytes_per_path, "algorithmic_bytes_per_path": bytes_per_path}})
     return out
 
 
-def run_steps(torch, world_obj, cam, params, accum, stream, steps, warmup):
-    """`warmup` untimed and `steps` timed single-GPU frames; returns (wall seconds, kernel ms list, last stats)."""
-    rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
-    for _ in range(warmup):
+class Ranks:
+    """The process group of one run: barrier, all-reduce of a frame's sums, max over ranks."""
+
+    def __init__(self, torch, dist, world):
+        self.torch, self.dist, self.world = torch, dist, world
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_seconds(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def timed_frames(ranks, rt, world_obj, cam, params, accum, stream, steps, warmup):
+    """`warmup` untimed and `steps` timed frames: each rank renders its samples, then the sums are
+    all-reduced (RCCL, ordered after the render on the same stream).  The timed frames are
+    bracketed by a barrier and a device synchronisation on both sides; the time is the maximum over
+    the ranks.  Returns a dict with the wall seconds, per-frame kernel and all-reduce milliseconds
+    and the last frame's statistics."""
+    torch = ranks.torch
+    kernel_ms, reduce_events, first_ms, last = [], [], None, None
+
+    def step(timed):
         accum.zero_()
-        world_obj.render_device(cam, params, accum.data_ptr(), stream, None)
-    torch.cuda.synchronize()
-    kernel_ms, last = [], None
+        stats = rt.rt_stats()
+        world_obj.render_device(cam, params, accum.data_ptr(), stream, stats)
+        if ranks.world > 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ranks.dist.all_reduce(accum)
+            b.record()
+            if timed:
+                reduce_events.append((a, b))
+        if timed:
+            kernel_ms.append(stats.kernel_ms)
+        return stats
+
+    for k in range(warmup):
+        s = step(False)
+        if k == 0:
+            first_ms = s.kernel_ms
+    ranks.fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        accum.zero_()
-        last = rt.rt_stats()
-        world_obj.render_device(cam, params, accum.data_ptr(), stream, last)
-        kernel_ms.append(last.kernel_ms)
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, kernel_ms, last
+        last = step(True)
+    ranks.fence()
+    elapsed = ranks.max_seconds(time.perf_counter() - t0)
+    return {"seconds": elapsed, "kernel_ms": kernel_ms, "all_reduce_ms": [a.elapsed_time(b) for a, b in reduce_events],
+            "first_frame_kernel_ms": first_ms, "last": last}
 
 
-def extra_configs(torch, rt, main_world, local_rank):
-    """Short single-GPU runs of the other BASELINE configurations (1 warm-up + 2 steps each)."""
+def run_config(ranks, rt, world_obj, rank, name, scene, nx, ny, cam_spec, spp, total_spp, steps, warmup, setup=None):
+    """One short run of another configuration; every rank takes part, rank 0 gets the record."""
+    torch = ranks.torch
+    cam = rt.camera(camera15(cam_spec, nx / ny))
+    accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")
+    s_begin, s_end = sample_range(rank, spp, ranks.world, total_spp)
+    frame_spp = total_spp if total_spp is not None else spp * ranks.world
+    params = world_obj.params(nx, ny, s_begin, s_end, seed=1, accum=rt.RT_ACCUM_F32)
+    t = timed_frames(ranks, rt, world_obj, cam, params, accum, torch.cuda.current_stream().cuda_stream, steps, warmup)
+    paths = nx * ny * frame_spp
+    rec = {"config": name, "scene": scene, "nx": nx, "ny": ny, "spp_per_gpu": s_end - s_begin, "spp_per_frame": frame_spp,
+           "scaling": "strong" if total_spp is not None else "weak", "value": paths * steps / t["seconds"] / 1e6, "unit": "Mpaths/s",
+           "ms_per_step": t["seconds"] / steps * 1e3, "kernel_ms": float(np.mean(t["kernel_ms"])), "kernel_ms_steps": t["kernel_ms"],
+           "rays_per_path": t["last"].rays / t["last"].paths, "mean_radiance": float(accum.mean().item()) / frame_spp,
+           "sample_range": [s_begin, s_end]}
+    if ranks.world > 1:
+        rec["all_reduce_ms"] = float(np.mean(t["all_reduce_ms"]))
+    if setup:
+        rec["setup_s"] = setup
+    del accum
+    return rec
+
+
+def extra_configs(ranks, rt, main_world, rank, local_rank):
+    """Short runs of the other BASELINE configurations (1 warm-up + 2 steps each).  One GPU: the
+    shares an 8-GPU split would give it, the book-2 scene, the 4K frame, the 10^6-sphere scene,
+    each with its own roofline.  Several GPUs: the weak-scaling figure (1024 samples per rank) and
+    the 3840x2160 frame's 4096 samples split across the ranks (BASELINE.json configs[3])."""
+    c5cam = CONFIGS["c5"]["camera"]
+    if ranks.world > 1:
+        cases = [("c2 weak: 1920x1080, 1024 spp on every GPU", "book1", 1920, 1080, 1024, None, "book", 2),
+                 (f"c4: 3840x2160, 4096 spp split over {ranks.world} GPUs", "book1", 3840, 2160, None, 4096, "book", 1)]
+    else:
+        cases = [("c2 at 128 spp (one GPU's share of 1024 spp split over 8)", "book1", 1920, 1080, 128, None, "book", 2),
+                 ("c2 at 16 spp", "book1", 1920, 1080, 16, None, "book", 2),
+                 ("c3: book-2 scene, moving spheres", "book2", 1920, 1080, 1024, None, "book", 2),
+                 ("c4 frame on one GPU: 3840x2160 at 512 spp (one GPU's share of 4096 split over 8)", "book1", 3840, 2160, 512, None, "book", 2),
+                 ("c5: 10^6 spheres, 64 spp", "stress:1000000", 1920, 1080, 64, None, c5cam, 2),
+                 ("c5: 10^6 spheres, 8 spp (one GPU's share of 64 split over 8)", "stress:1000000", 1920, 1080, 8, None, c5cam, 2)]
     out = []
-    cases = [
-        ("c2 at 128 spp (one GPU's share of 1024 spp split over 8)", "book1", 1920, 1080, 128, "book"),
-        ("c2 at 16 spp", "book1", 1920, 1080, 16, "book"),
-        ("c3: book-2 scene, moving spheres", "book2", 1920, 1080, 1024, "book"),
-        ("c4 frame on one GPU: 3840x2160 at 512 spp (one GPU's share of 4096 split over 8)", "book1", 3840, 2160, 512, "book"),
-        ("c5: 10^6 spheres, 64 spp", "stress:1000000", 1920, 1080, 64, CONFIGS["c5"]["camera"]),
-        ("c5: 10^6 spheres, 8 spp (one GPU's share of 64 split over 8)", "stress:1000000", 1920, 1080, 8, CONFIGS["c5"]["camera"]),
-    ]
     worlds = {"book1": (main_world, None)}
-    stream = torch.cuda.current_stream().cuda_stream
-    for name, scene, nx, ny, spp, cam_spec in cases:
+    counts = {}
+    for name, scene, nx, ny, spp, total_spp, cam_spec, steps in cases:
         if scene not in worlds:
             t0 = time.perf_counter()
             if scene.startswith("stress:"):      # generated in memory: scene API objects -> reference BVH build -> layout -> upload
@@ -235,22 +336,54 @@ def extra_configs(torch, rt, main_world, local_rank):
                 w_new = rt.World(scene_file(rt, scene), device=local_rank)
             worlds[scene] = (w_new, dict(w_new.setup_seconds(), total_s=time.perf_counter() - t0))
         w, setup = worlds[scene]
-        cam = rt.camera(camera15(cam_spec, nx / ny))
-        accum = torch.zeros(ny, nx, 3, dtype=torch.float32, device="cuda")
-        params = w.params(nx, ny, 0, spp, seed=1, accum=rt.RT_ACCUM_F32)
-        wall, kms, last = run_steps(torch, w, cam, params, accum, stream, 2, 1)
-        paths = nx * ny * spp
-        rec = {"config": name, "scene": scene, "nx": nx, "ny": ny, "spp": spp, "value": paths * 2 / wall / 1e6, "unit": "Mpaths/s",
-               "ms_per_step": wall / 2 * 1e3, "kernel_ms": float(np.mean(kms)), "rays_per_path": last.rays / last.paths,
-               "mean_radiance": float(accum.mean().item()) / spp}
-        if setup:
-            rec["setup_s"] = setup
+        rec = run_config(ranks, rt, w, rank, name, scene, nx, ny, cam_spec, spp, total_spp, steps, 1, setup)
+        if rank == 0 and ranks.world == 1:
+            if (scene, cam_spec) not in counts:
+                path = scene_file(rt, scene)
+                counts[(scene, cam_spec)] = algorithmic_counts(path, camera15(cam_spec, nx / ny))
+                if scene.startswith("stress:"):
+                    os.unlink(path)
+            b, e = rec["sample_range"]
+            rec["roofline"] = roofline(f"{scene} {nx}x{ny} samples [{b},{e})", counts[(scene, cam_spec)], nx * ny * (e - b), e - b, rec["kernel_ms_steps"])
         out.append(rec)
-        del accum
     for scene, (w, setup) in worlds.items():
         if setup is not None:
             w.close()
     return out
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """Starts ranks 0..n-1 of `script` (this file) as fresh child processes, one per GPU, with the
+    rendezvous variables torch.distributed reads, and waits for them.  The caller must not have
+    touched the GPU: nothing here replaces a process that has.  Rank 0's standard output is this
+    process's.  When a rank fails the others are given ten seconds and then ended (by their own
+    process ids).  Returns the largest exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        # (only rank 0 reports: what another rank or its libraries print goes to standard error)
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *argv], env=env, stdout=None if r == 0 else sys.stderr))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.05)
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if (failed_at is not None and time.monotonic() - failed_at > 10) or (deadline is not None and time.monotonic() > deadline):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            if failed_at is None:
+                failed_at = time.monotonic()
+    codes = [p.wait() for p in procs]
+    return max((c if c >= 0 else 128 - c) for c in codes)
 
 
 def main():
@@ -263,7 +396,7 @@ def main():
     ap.add_argument("--nx", type=int, default=None)
     ap.add_argument("--ny", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU per step (weak scaling)")
-    ap.add_argument("--total-spp", type=int, default=None, help="samples per pixel per step in all, split across the GPUs (strong scaling)")
+    ap.add_argument("--total-spp", type=int, default=None, help="samples per pixel per step in all, split across the GPUs (strong scaling; the default with several GPUs: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configurations")
     ap.add_argument("--timed-only", action="store_true", help="profiling runs: nothing but the warm-up and the timed steps touches the GPU")
@@ -272,6 +405,18 @@ def main():
     ap.add_argument("--camera", default=None, help="book (main.cpp:114-120) or 'fx,fy,fz,ax,ay,az,vfov'")
     ap.add_argument("--dump-accum", default=None, help="rank 0 writes the reduced float sums of the last step to this .npy file")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has not imported torch)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without RANK set")
+
     cfg = dict(CONFIGS[args.config or "c2"])
     for k in ("scene", "nx", "ny", "camera"):
         if getattr(args, k) is not None:
@@ -280,6 +425,8 @@ def main():
         cfg["total_spp"], cfg["spp"] = args.total_spp, None
     elif args.spp is not None:
         cfg["spp"], cfg["total_spp"] = args.spp, None
+    elif world > 1 and cfg["total_spp"] is None:
+        cfg["total_spp"], cfg["spp"] = cfg["spp"], None      # several GPUs split the frame's samples
     if args.timed_only:
         args.no_cpu_baseline = args.no_extra = True
     scene, nx, ny = cfg["scene"], cfg["nx"], cfg["ny"]
@@ -288,11 +435,6 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -301,6 +443,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+    ranks = Ranks(torch, dist, world)
 
     rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
     cam15 = camera15(cfg["camera"], nx / ny)
@@ -319,82 +462,21 @@ def main():
     my_spp = s_end - s_begin
     frame_spp = cfg["total_spp"] if strong else cfg["spp"] * world
     params = w.params(nx, ny, s_begin, s_end, seed=1, accum=rt.RT_ACCUM_F32)
-    kernel_ms = []
-
-    def step(record):
-        accum.zero_()
-        stats = rt.rt_stats() if record else None
-        w.render_device(cam, params, accum.data_ptr(), stream, stats)
-        if world > 1:
-            dist.all_reduce(accum)          # RCCL sum over xGMI, ordered after the render on the same stream
-        if record:
-            kernel_ms.append(stats.kernel_ms)
-            return stats
-        return None
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    first_frame_ms = None      # the first frame of a view also measures its tile costs; later frames reuse the order
-    for k in range(args.warmup):
-        if k == 0:
-            first_frame_ms = step(True).kernel_ms
-            kernel_ms.clear()
-        else:
-            step(False)
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t = timed_frames(ranks, rt, w, cam, params, accum, stream, args.steps, args.warmup)
+    elapsed, kernel_ms, last = t["seconds"], t["kernel_ms"], t["last"]
 
     paths_per_step = nx * ny * frame_spp
     value = paths_per_step * args.steps / elapsed / 1e6
     mean = float(accum.mean().item()) / frame_spp
     if rank == 0 and args.dump_accum:
         np.save(args.dump_accum, accum.cpu().numpy())
+    extras = None
+    if not args.no_extra:
+        extras = extra_configs(ranks, rt, w, rank, local_rank)
 
     if rank == 0:
         counts = algorithmic_counts(scene_path, cam15)
-        bytes_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 32 + counts["sphere_tests_per_ray"] * 16 +
-                                                    counts["moving_tests_per_ray"] * 40) + 12.0 / max(1, my_spp)
-        flops_per_path = counts["rays_per_path"] * (counts["box_tests_per_ray"] * 27 + (counts["sphere_tests_per_ray"] +
-                                                    counts["moving_tests_per_ray"]) * 30 + 60)
-        k_s = float(np.mean(kernel_ms)) / 1e3
-        launch_paths = nx * ny * my_spp
-        alg_gbs = launch_paths * bytes_per_path / k_s / 1e9
         config_key = f"{scene} {nx}x{ny} samples [{s_begin},{s_end})"
-        # HBM bytes of one launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE doubled for
-        # gfx950 + WRITE_SIZE); only valid for the configuration it was collected on
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("config_key") == config_key:
-                traffic = tj["hbm_bytes_per_launch"]
-        algorithmic_hbm = {"what": "REFERENCE-traversal bytes (32 B per box test, 16 B per static-sphere test, 40 B per moving-sphere test, 12 B of "
-                                   "framebuffer per pixel; counts of the reference's both-children walk measured by the oracle) / kernel time, against HBM "
-                                   "peak: reference-work-equivalents that this kernel neither fetches (the tree is in LDS) nor executes; may exceed 1",
-                           "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
-                           "algorithmic_bytes_per_launch": launch_paths * bytes_per_path, "algorithmic_bytes_per_path": bytes_per_path, "counts": counts,
-                           "reference_flops": {"achieved_tflops": launch_paths * flops_per_path / k_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
-                                               "frac": launch_paths * flops_per_path / k_s / 1e12 / FP64_PEAK_TFLOPS}}
-        roofline = valu_roofline(config_key, k_s)
-        if roofline is None:   # no PMC pass on file for this configuration: only the measured HBM side can be stated
-            roofline = {"bound": "valu", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                        "meaning": f"no PMC pass over '{config_key}' in profiles/valu.json (tools/profile_round.sh collects it for the default configuration)"}
-        roofline.update({"traffic": traffic, "traffic_unit": "HBM bytes per step: costing pass + main launch (PMC, profiles/traffic.json)",
-                         "hbm_frac": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": "k_render (+ its costing pass and tile sort)", "kernel_ms": k_s * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                         "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms], "algorithmic_hbm": algorithmic_hbm})
         metric = "Mpaths/s at 1080p random-spheres" if (nx, ny) == (1920, 1080) else f"Mpaths/s at {nx}x{ny} random-spheres"
         line = {
             "metric": metric, "value": value, "unit": "Mpaths/s", "n_gpus": world,
@@ -405,22 +487,29 @@ def main():
                                    + ", max depth 50, BVH built by the reference algorithm)",
                        "nx": nx, "ny": ny, "spp_per_gpu": my_spp, "spp_per_frame": frame_spp,
                        "parallelism": f"sample-split x{world}, RCCL all-reduce of f32 sums"},
-            "first_frame_kernel_ms": first_frame_ms,
+            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+                      "launched_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or ("bench.py" if world > 1 else None)},
+            "first_frame_kernel_ms": t["first_frame_kernel_ms"],
             "tile_order": "the warm-up frame measures the tile costs (one more short launch); the timed frames, same view, reuse its order",
             "rays_per_path": last.rays / last.paths, "mean_radiance": mean, "scene_build_upload_s": t_build, "scene_setup": w.setup_seconds(),
-            "roofline": roofline,
+            "roofline": roofline(config_key, counts, nx * ny * my_spp, my_spp, kernel_ms),
         }
+        if world > 1:
+            line["all_reduce_ms_per_step"] = float(np.mean(t["all_reduce_ms"])) if t["all_reduce_ms"] else None
+            line["all_reduce_ms_steps"] = [round(float(x), 3) for x in t["all_reduce_ms"]]
+            line["all_reduce_bytes"] = nx * ny * 3 * 4
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene_path, cam15, nx, ny)
         if world == 1 and not args.timed_only:
             line["image_check"] = image_check(rt, w, scene)
-        if world == 1 and not args.no_extra:
-            line["extra_configs"] = extra_configs(torch, rt, w, local_rank)
+        if extras is not None:
+            line["extra_configs"] = extras
         print(json.dumps(line), flush=True)
     w.close()
     if scene.startswith("stress:") and scene_path:
         os.unlink(scene_path)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

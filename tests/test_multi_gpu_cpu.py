@@ -73,3 +73,46 @@ def test_two_ranks_split_one_frames_samples(orc, tmp_path):
     got = np.load(out)
     whole, _ = orc.Scene(recipe("mixed")).render(golden("frames")["camera"], 32, 16, 0, 7, 99, orc.ORC_RNG_STREAM)
     np.testing.assert_allclose(got, whole.astype(np.float32), rtol=2e-6, atol=1e-6)
+
+
+RANK_STUB = r"""
+import os, sys
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if "--fail" in sys.argv and rank == 1:
+    sys.exit(3)
+dist.init_process_group("gloo")
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+if rank == 0:
+    print("sum", t.item(), dist.get_world_size(), *sys.argv[1:], flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    # `python bench.py --gpus N` without a launcher: launch_ranks starts N fresh processes with the
+    # rendezvous variables set; here they run a stand-in script over gloo (bench.py itself needs a GPU)
+    import subprocess
+    stub = tmp_path / "stub.py"
+    stub.write_text(RANK_STUB)
+    code = "import sys; sys.path.insert(0, sys.argv[1]); import bench; sys.exit(bench.launch_ranks(2, ['--x', '1'], script=sys.argv[2], timeout=120))"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code, ROOT, str(stub)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    report = [l for l in r.stdout.splitlines() if l.startswith("sum")]      # (gloo prints its own connection notes)
+    assert report == ["sum 3.0 2 --x 1"]
+
+
+def test_a_failing_rank_ends_the_launch(tmp_path):
+    import subprocess
+    import time
+    stub = tmp_path / "stub.py"
+    stub.write_text(RANK_STUB)
+    code = "import sys; sys.path.insert(0, sys.argv[1]); import bench; sys.exit(bench.launch_ranks(2, ['--fail'], script=sys.argv[2], timeout=120))"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-c", code, ROOT, str(stub)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0          # rank 1's exit code 3, or rank 0 ended while it waited for its peer
+    assert time.monotonic() - t0 < 100

@@ -64,11 +64,12 @@ def test_two_ranks_on_one_gpu_sum_to_one_rank(rt, tmp_path):
     # each rank renders half of the 8 samples with the real kernel; the reduced buffer must be the
     # frame one process renders with all 8 (the halves are rounded to float before they are added).
     out = str(tmp_path / "sum.npy")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", _port(1), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    # (plain `python bench.py --gpus 2`: bench.py starts its two ranks itself, as the driver's command does)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--scene", "book2", "--nx", "320", "--ny", "180", "--total-spp", "8", "--backend", "gloo", "--share-device",
            "--timed-only", "--dump-accum", out]
-    r = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    env = {k: v for k, v in ENV.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["spp_per_gpu"] == 4 and line["config"]["spp_per_frame"] == 8
@@ -84,6 +85,22 @@ def test_two_ranks_on_one_gpu_sum_to_one_rank(rt, tmp_path):
     assert np.array_equal(got, a + b)                                   # exactly the two ranks' float buffers, added
     np.testing.assert_allclose(got, whole, rtol=3e-7, atol=1e-6)       # = the whole frame up to float rounding
     assert abs(line["mean_radiance"] - whole.mean() / 8) < 1e-6
+    assert line["ranks"]["world_size"] == 2 and line["ranks"]["launched_by"] == "bench.py" and line["all_reduce_ms_per_step"] is not None
+
+
+def test_two_ranks_under_torch_distributed_run(tmp_path):
+    # the same two ranks started by torch.distributed.run, as the driver's multi-GPU command does; several
+    # GPUs and no sample flags: the frame's 1024 samples are split (here a small frame of the book-1 scene)
+    out = str(tmp_path / "sum.npy")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _port(1), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--nx", "64", "--ny", "36", "--backend", "gloo", "--share-device", "--timed-only", "--dump-accum", out]
+    r = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["spp_per_gpu"] == 512 and line["config"]["spp_per_frame"] == 1024
+    assert line["roofline"]["frac"] > 0 and line["ranks"]["launched_by"] == "torch.distributed.run"
+    assert np.load(out).shape == (36, 64, 3)
 
 
 def test_4k_frame_properties(rt):

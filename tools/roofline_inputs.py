@@ -5,7 +5,9 @@ usage: tools/roofline_inputs.py PMC_DIR OUT_DIR CONFIG_KEY TAG
 
 Takes every counter from the last main k_render launch of its pass (the passes run one warm-up frame,
 which measures the tile costs, and one frame like the benchmark's timed ones, which reuses the tile
-order: one launch, what rt_stats.kernel_ms times) and writes OUT_DIR/valu.json and OUT_DIR/traffic.json.
+order: one launch, what rt_stats.kernel_ms times) and enters them under CONFIG_KEY into
+OUT_DIR/valu.json and OUT_DIR/traffic.json ({"configs": {CONFIG_KEY: {...}}}; other keys already in
+those files are kept).
 
 Units (checked against tools/microbench/valu_rates under the same counters): the SQ cycle
 counters tick once per 4 clocks; SQ_THREAD_CYCLES_VALU adds, per VALU instruction pass, the
@@ -22,6 +24,16 @@ import re
 import sys
 
 N_XCD, N_SIMD = 8, 1024
+
+
+def merge(path, config_key, record):
+    doc = {"configs": {}}
+    if os.path.exists(path):
+        old = json.load(open(path))
+        if "configs" in old:
+            doc = old
+    doc["configs"][config_key] = record
+    json.dump(doc, open(path, "w"), indent=1)
 
 
 def main():
@@ -48,7 +60,7 @@ def main():
     clocks = g("GRBM_GUI_ACTIVE") / N_XCD                    # shader clocks the frame's kernels were resident
     lanes = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
     valu = {
-        "config_key": config_key, "source": f"{tag}/pmc1024 (tools/pmc_profile.sh --spp 1024; the second frame's k_render launch)",
+        "config_key": config_key, "source": f"{tag}/{os.path.basename(pmc_dir.rstrip('/'))} (tools/pmc_profile.sh; the second frame's k_render launch)",
         "SQ_THREAD_CYCLES_VALU": g("SQ_THREAD_CYCLES_VALU"), "SQ_ACTIVE_INST_VALU": g("SQ_ACTIVE_INST_VALU"), "SQ_INSTS_VALU": g("SQ_INSTS_VALU"),
         "SQ_WAVE_CYCLES": g("SQ_WAVE_CYCLES"), "SQ_WAVES": g("SQ_WAVES"), "GRBM_GUI_ACTIVE": g("GRBM_GUI_ACTIVE"),
         "lanes_active": lanes,                                                     # of 64, per VALU instruction
@@ -65,12 +77,12 @@ def main():
         valu["f64_insts_per_launch"] = {"add": f64[0], "mul": f64[1], "fma": f64[2], "trans": f64[3]}
         # wave-instructions x the mean lane count of all VALU instructions (the counters do not split lanes by class)
         valu["f64_flops_per_launch"] = (f64[0] + f64[1] + 2 * f64[2] + f64[3]) * lanes
-    json.dump(valu, open(os.path.join(out_dir, "valu.json"), "w"), indent=1)
+    merge(os.path.join(out_dir, "valu.json"), config_key, valu)
     print(json.dumps(valu))
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-        traffic = {"config_key": config_key, "source": f"{tag}/pmc1024", "FETCH_SIZE_KiB": g("FETCH_SIZE"), "WRITE_SIZE_KiB": g("WRITE_SIZE"),
+        traffic = {"config_key": config_key, "source": f"{tag}/{os.path.basename(pmc_dir.rstrip('/'))}", "FETCH_SIZE_KiB": g("FETCH_SIZE"), "WRITE_SIZE_KiB": g("WRITE_SIZE"),
                    "hbm_bytes_per_launch": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024}
-        json.dump(traffic, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+        merge(os.path.join(out_dir, "traffic.json"), config_key, traffic)
         print(json.dumps(traffic))
 
 
