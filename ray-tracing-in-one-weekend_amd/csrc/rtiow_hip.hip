@@ -590,7 +590,8 @@ struct rt_scene {
     dev_buf<uint32_t> tiles;                 // per tile: measured cost, then the render order
     size_t tiles_capacity = 0;
     // the frame whose tile order `tiles` holds: a frame of the same view and size reuses it
-    struct order_key { rt_camera camera; uint32_t nx, ny, max_depth, tile_shift; double t_min; } order_of{};
+    // (and the stream that wrote it: a frame queued on another stream could overtake the sort)
+    struct order_key { rt_camera camera; uint32_t nx, ny, max_depth, tile_shift; double t_min; void *stream; } order_of{};
     bool order_valid = false;
     // static scenes whose sphere boxes carry the far slack: frames whose camera lies within
     // far_free_radius of far_free_centre render without the per-segment slack (0: never)
@@ -679,6 +680,9 @@ struct flattener {
         double own[6];
         for (int a = 0; a < 3; ++a) { own[2 * a] = nd.box_min[a]; own[2 * a + 1] = nd.box_max[a]; }
         if (ref[0] < 0 && ref[1] < 0) return leaf_of(~ref[0], ~ref[1], own, safe);   // bvh_node.cpp:31-37
+        // one object that is itself a subtree, as both children (bvh_node.cpp:31-34): trying it twice finds the
+        // same hit twice, and this node's box is the subtree's own
+        if (ref[0] == ref[1]) return build(ref[0], depth + 1, safe);
 
         if (depth + 1 > max_depth) max_depth = depth + 1;
         const int me = (int)nodes.size();
@@ -738,6 +742,7 @@ struct flattener {
             return;
         }
         for (int c = 0; c < 2; ++c) {
+            if (c == 1 && ref[1] >= 0 && ref[1] == ref[0]) break;   // one object as both children (bvh_node.cpp:31-34): its leaves once
             if (ref[c] >= 0) collect(ref[c], depth + 1);
             else {   // a primitive beside a subtree is tested whenever this node's box is hit
                 lr.ref = leaf_of(~ref[c], ~ref[c], lr.box, lr.safe);
@@ -1087,6 +1092,10 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         return scene_create(desc, device, out);
     } catch (const std::bad_alloc &) {   // the flattened tree is built in host vectors
         return fail(RT_E_INVALID, "rt_scene_create: out of host memory");
+    } catch (const std::exception &e) {  // e.g. std::system_error when the build's helper threads cannot be started
+        return fail(RT_E_DEVICE, "rt_scene_create: %s", e.what());
+    } catch (...) {
+        return fail(RT_E_DEVICE, "rt_scene_create: unknown failure while laying out the tree");
     }
 }
 
@@ -1300,22 +1309,38 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         for (int k = 0; k < 3; ++k)
             if (desc->materials[i].kind == RT_MAT_METAL && !(desc->materials[i].albedo[k] >= 0 && desc->materials[i].albedo[k] <= 1)) s->d.wide_radiance = 1;
+    // (a Perlin texture's colour is a blend, with weights in [0, 1], of the caller's table values: perlin.cpp:33-47)
+    for (uint32_t i = 0; i < desc->n_textures; ++i)
+        if (desc->textures[i].kind == RT_TEX_PERLIN)
+            for (int k = 0; k < 256; ++k)
+                if (!(ranfloat[(size_t)k] >= 0 && ranfloat[(size_t)k] <= 1)) s->d.wide_radiance = 1;
     // RTIOW_RECHECK_ALL_LEAVES makes every hit of the static-scene variant take its second, exact
     // walk (tests).
     {
         s->render_defer = static_scene;
         s->d.recheck_all = getenv("RTIOW_RECHECK_ALL_LEAVES") ? 1u : 0u;
     }
-    {   // the reach of the moving spheres, per axis: |c(t) - c0| <= |dc| |t - time0| / |time1 - time0| <= reach_a |t| + reach_b
+    {   // The reach of the moving spheres: how far, per axis, a sphere at ray time t can stick out of the box
+        // the walk tests before it is tried -- the box of its leaf, whatever the caller put there (the
+        // reference's covers the positions at the bvh's own times, moving_sphere.cpp:51-60, which need not
+        // be the sphere's time0 and time1).  Along axis k the centre is m + v t with v = dc / (time1 -
+        // time0) and m = c0 - v time0, so the sphere's high side exceeds the box's by (m + r - hi) + v t
+        // <= max(0, m + r - hi) + |v| |t|, the low side likewise: reach_a = max |v|, reach_b = the largest
+        // excess at t = 0.  Every box above a leaf contains the leaf's, so the bound holds for them too.
         auto up = [](double v) { const float f = (float)v; return (double)f < v ? nextafterf(f, HUGE_VALF) : f; };
+        auto worst = [](double now, double v) { return (v >= now) ? v : (std::isnan(v) ? HUGE_VAL : now); };   // (a zero time span: infinite or NaN)
         for (int k = 0; k < 3; ++k) {
             double a = 0, b = 0;
-            for (const DPrim &p : fl.prims) {
+            for (size_t i = 0; i < fl.prims.size(); ++i) {
+                const DPrim &p = fl.prims[i];
                 if (p.orig < 0 || p.kind == PK_STATIC) continue;
-                const double len = std::fabs(p.dc[k]), span = std::fabs(p.t1 - p.t0);
-                const double pa = len / span, pb = len * std::fabs(p.t0) / span;   // (a zero span: infinite or NaN)
-                a = (pa >= a) ? pa : (std::isnan(pa) ? HUGE_VAL : a);
-                b = (pb >= b) ? pb : (std::isnan(pb) ? HUGE_VAL : b);
+                const double *box = fl.leaf_boxes[i / 2].box;
+                const double v = p.dc[k] / (p.t1 - p.t0), m = p.c0[k] - v * p.t0, r = std::fabs(p.r);
+                // (these sums are rounded, as are the reference's when it forms the box: 2^-40 of the magnitudes covers both)
+                const double pad = 0x1p-40 * (std::fabs(m) + r);
+                a = worst(a, std::fabs(v));
+                b = worst(b, (m + r) - box[2 * k + 1] + pad);
+                b = worst(b, box[2 * k] - (m - r) + pad);
             }
             s->d.reach_a[k] = up(a * (1 + 0x1p-20));
             s->d.reach_b[k] = up(b * (1 + 0x1p-20));
@@ -1622,7 +1647,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     bool order_on_file = false;
     if (f.ordered) {
         rt_scene::order_key key{};
-        key.camera = *camera; key.nx = pr->nx; key.ny = pr->ny; key.max_depth = pr->max_depth; key.tile_shift = f.tile_shift; key.t_min = pr->t_min;
+        key.camera = *camera; key.nx = pr->nx; key.ny = pr->ny; key.max_depth = pr->max_depth; key.tile_shift = f.tile_shift; key.t_min = pr->t_min; key.stream = stream_v;
         const char *reuse = getenv("RTIOW_TILE_COST_REUSE");
         order_on_file = scene->order_valid && memcmp(&key, &scene->order_of, sizeof key) == 0 && !(reuse && atoi(reuse) == 0) && !getenv("RTIOW_TILE_PROBE");
         scene->order_of = key;

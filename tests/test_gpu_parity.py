@@ -109,7 +109,9 @@ def _random_recipe(rng, path, moving=True):
             lines.append(sphere())
         else:
             n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 17, 40, 150]))
-            lines.append(f"bvh_begin {int(rng.integers(1, 1000))} 0 1")
+            # (the bvh's own times decide which positions the moving spheres' boxes cover: moving_sphere.cpp:51-60)
+            t0, t1 = [(0, 1), (0, 1), (1, 2), (-3, -1), (0.25, 0.75), (2, 2)][int(rng.integers(0, 6))] if moving else (0, 1)
+            lines.append(f"bvh_begin {int(rng.integers(1, 1000))} {t0} {t1}")
             k = 0
             while k < n:
                 if rng.random() < 0.15:     # an object_list as one object of the bvh_node (1 to 5 members)
@@ -162,6 +164,79 @@ def test_random_worlds_against_oracle(rt, orc, tmp_path):
             m = hit == 1
             assert np.array_equal(h["t"][m], tpn[m, 0]), (k, layout)
             assert np.array_equal(h["p"][m], tpn[m, 1:4]) and np.array_equal(h["normal"][m], tpn[m, 4:7]), (k, layout)
+
+
+@pytest.mark.parametrize("times", [(1, 2), (-3, -1), (0, 1), (0.5, 0.5)])
+def test_moving_spheres_under_other_bvh_times(rt, orc, tmp_path, times):
+    # A bvh_node built for times other than its spheres' own (bvh_node.hpp:17 takes any): the boxes then
+    # surround where the spheres are at THOSE times (moving_sphere.cpp:51-60), far from where a ray of
+    # time 0 finds them.  The reference tries a sphere whenever the ray crosses its box and takes the
+    # nearest hit, wherever the sphere is by then -- also in front of a static sphere that the ray meets
+    # before it reaches the box.  Rows of (moving sphere, static sphere in its way), rays along the rows.
+    lines = ["rtiow-recipe 1", "texture constant 0.5 0.5 0.5", "material lambertian 0", f"bvh_begin 7 {times[0]} {times[1]}"]
+    rows = 24
+    for k in range(rows):
+        y, z = 3.0 * (k % 6), 3.0 * (k // 6)
+        lines.append(f"moving_sphere 0 0 {y} {z} 4 {y} {z} 0 1 1")          # at x = 4 t
+        lines.append(f"sphere 0 2 {y} {z} 0.5")                             # between x = 1.5 and 2.5
+        lines.append(f"sphere 0 -6 {y} {z} 0.5")
+    lines.append("bvh_end")
+    path = tmp_path / "times.recipe"
+    path.write_text("\n".join(lines) + "\n")
+    rng = np.random.default_rng(11)
+    n = 40000
+    k = rng.integers(0, rows, n)
+    o = np.stack([rng.uniform(-12, 12, n), 3.0 * (k % 6) + rng.uniform(-1.2, 1.2, n), 3.0 * (k // 6) + rng.uniform(-1.2, 1.2, n)], axis=1)
+    d = np.stack([rng.choice([-1.0, 1.0], n) * rng.uniform(0.5, 2, n), rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n)], axis=1)
+    rays = np.hstack([o, d, rng.uniform(-1, 1, (n, 1))])
+    hit, prim, tpn = orc.Scene(str(path)).trace(rays, 0.001, np.finfo(np.float64).max)
+    moving_hits = (hit == 1) & (prim % 3 == 0)
+    assert moving_hits.mean() > 0.02
+    w = rt.World(str(path))
+    try:
+        h = w.trace(rays, 0.001, np.finfo(np.float64).max)
+        cam15 = np.array([-14, 7.5, 4.5, 0, 7.5, 4.5, 0, 1, 0, 60, 2.0, 0.0, 10, 0, 1], dtype=np.float64)
+        got, st = w.render(rt.camera(cam15), 80, 40, 0, 4, 5, rt.RT_ACCUM_F64)
+    finally:
+        w.close()
+    assert np.array_equal(h["hit"], hit.astype(np.int32)) and np.array_equal(h["prim"], prim)
+    m = hit == 1
+    assert np.array_equal(h["t"][m], tpn[m, 0]) and np.array_equal(h["normal"][m], tpn[m, 4:7])
+    exp, counters = orc.Scene(str(path)).render(cam15, 80, 40, 0, 4, 5, orc.ORC_RNG_STREAM)
+    assert st.rays == counters.rays
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+
+
+def test_a_list_as_the_only_object_of_a_half(rt, orc, tmp_path, monkeypatch):
+    # bvh_node.cpp:31-34: a span of one object makes that object both children.  When the object is an
+    # object_list its subtree hangs under the node twice in the description; the device tree must hold
+    # it once (same hits, no doubled tables), under both layouts.  Group 1: a list alone in its bvh_node.
+    # Group 2: three objects whose first half (one object, whatever the axis) is a list.
+    lines = ["rtiow-recipe 1", "texture constant 0.5 0.5 0.5", "material lambertian 0", "material metal 0.8 0.8 0.8 0.1",
+             "bvh_begin 3 0 1", "list_begin", "sphere 0 0 0 0 0.5", "sphere 1 0.6 0 0 0.5", "moving_sphere 0 1.2 0 0 1.2 0.4 0 0 1 0.5", "list_end", "bvh_end",
+             "bvh_begin 4 0 1", "list_begin", "sphere 0 -9 -9 -9 0.5", "sphere 1 -9.5 -9.2 -9.1 0.7", "sphere 0 -8.8 -9 -9.3 0.4", "sphere 0 -9 -9 -9 0.5", "list_end",
+             "sphere 1 3 3 3 0.5", "sphere 0 4 4 4 0.5", "bvh_end"]
+    path = tmp_path / "halves.recipe"
+    path.write_text("\n".join(lines) + "\n")
+    rng = np.random.default_rng(5)
+    n = 30000
+    tgt = np.where(rng.random((n, 1)) < 0.5, np.array([[0.6, 0, 0]]), np.array([[-9.1, -9.1, -9.1]])) + rng.uniform(-1, 1, (n, 3))
+    o = tgt + rng.uniform(-6, 6, (n, 3))
+    rays = np.hstack([o, tgt - o, rng.uniform(-1, 1, (n, 1))])
+    hit, prim, tpn = orc.Scene(str(path)).trace(rays, 0.001, np.finfo(np.float64).max)
+    assert 0.3 < (hit == 1).mean() < 0.99
+    tables = {}
+    for layout in ("", "reference"):
+        if layout:
+            monkeypatch.setenv("RTIOW_TREE", layout)
+        w = rt.World(str(path))
+        try:
+            h = w.trace(rays, 0.001, np.finfo(np.float64).max)
+        finally:
+            w.close()
+        assert np.array_equal(h["hit"], hit.astype(np.int32)) and np.array_equal(h["prim"], prim), layout
+        m = hit == 1
+        assert np.array_equal(h["t"][m], tpn[m, 0]) and np.array_equal(h["normal"][m], tpn[m, 4:7]), layout
 
 
 def test_degenerate_rays(worlds, orc):
