@@ -39,6 +39,20 @@ static_assert(sizeof(DNode) == 64, "DNode is one 64-byte line");
 
 struct DLeaf { double box[6]; };
 
+// The four-wide tree of scenes without moving spheres: the binary tree with every other level folded
+// away (flattener::collapse), so that a walk takes half as many dependent steps.  A node holds the boxes
+// of up to four children, plane by plane -- the four children's min x, then their max x, min y, ... --
+// so that the four planes a ray meets first on an axis are ONE 16-byte read at an address chosen by the
+// direction's sign (the swap of aabb.cpp:16-18).  The boxes are the binary tree's (single precision,
+// moved and rounded outward), the test is node_test's.  An empty slot has child = REF_NONE and an
+// inverted box.  128 bytes: one cache line per step for trees that live in device memory.
+struct __attribute__((aligned(16))) DNode4 {
+    float pl[6][4];     // [min x, max x, min y, max y, min z, max z][child]
+    int32_t child[4];   // >= 0 DNode4 index, < 0 leaf reference, REF_NONE = no child
+    uint32_t pad[4];
+};
+static_assert(sizeof(DNode4) == 128, "DNode4 is one 128-byte line");
+
 // A plane of an inner box in single precision: moved outward by 2^-22 of its magnitude (the part of
 // the conservative test's error bound that is proportional to plane / d, see make_ctx), then
 // rounded outward.
@@ -85,7 +99,8 @@ static_assert(sizeof(DPrim) == 96, "DPrim layout");
 
 // One entry of the world's object_list.  ref is a node index or a leaf reference;
 // has_box = 0 for a bare primitive in the list (object_list.cpp:18 tries it directly).
-struct DItem { int32_t ref; uint32_t has_box; };
+// ref4: the same item in the four-wide tree (a DNode4 index, or the same leaf reference), where the scene has one.
+struct DItem { int32_t ref; uint32_t has_box; int32_t ref4; uint32_t pad; };
 // inv_ri = 1 / ri and r0sq = ((1 - ri) / (1 + ri))^2, as material.cpp:81 and :27-28 form them on every
 // call, are formed once at upload
 struct DMat { uint32_t kind; uint32_t tex; double albedo[3]; double fuzz; double ri; double inv_ri; double r0sq; };
@@ -109,8 +124,10 @@ struct FarSlack {
     float k;            // 2^-49 / smallest radius, rounded up; 0 = the scene needs none
 };
 
+struct DNode4;
 struct DScene {
     const DNode *nodes;
+    const DNode4 *nodes4;     // the four-wide tree of scenes without moving spheres (null: none)
     const DLeaf *leaves;
     const DPrim *prims;       // 2 per leaf
     const DItem *items;
@@ -830,6 +847,7 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
 #pragma unroll
                         for (int extra = 0; extra < kExtraNodeSteps; ++extra) {
                             if (tv.cur >= 0) {   // (REF_NONE is negative)
+                                stats.add(0, (uint32_t)__popcll(__ballot(true)));
                                 if (COUNT_WORK) work += 1;
                                 if (LDS_TREE) node_step_lds<SPILL, true, DEFER>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
                                 else if (tv.cur < tree.n_lnodes) node_step_lds<SPILL, false, DEFER>(tree.lnodes, pa, r, tmin_below, tmax_above, st, tv);
@@ -848,6 +866,329 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
                 item_begin(sc, i, r, tmin, closest, tv);
                 if (LDS_TREE && tv.cur >= 0) tv.cur *= (int32_t)LNODE_STRIDE;
             }
+        }
+        if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
+    }
+    t_out = closest;
+    prim_out = found;
+    return found >= 0;
+}
+
+// ------------------------------------------------------------ four-wide walk ----
+// The walk of world_closest_voted over DNode4 nodes (scenes without moving spheres: DEFER's rules,
+// every sphere behind a box of its own, every subtree skipped behind the best hit).  One step tests
+// the boxes of up to four children, goes on with the nearest one hit and pushes the others, farthest
+// first.  Which candidates a walk finds does not depend on the order, and the nearest candidate wins
+// with the later primitive among equals (take_if_closer): the answer is the binary walk's.
+//
+// Trees that live in LDS whole keep 16-bit child words, so that a child and the distance at which its
+// box is entered travel in ONE 32-bit key -- the top 16 bits of the entry distance (a positive float:
+// its bit pattern orders like its value; 8 bits of mantissa are plenty for an ordering that is only a
+// heuristic) above the child word -- and sorting the four keys with five min/max pairs sorts the
+// children; a miss is the key 0xFFFFFFFF, which is also what an empty slot's word makes of any key.
+//   child word: node -> byte offset of its record / 16; leaf -> 0x8000 | (2 leaf + second sphere);
+//   a walk's `cur` is the word sign-extended from 16 bits: >= 0 node, < 0 leaf, -1 = nothing left
+#ifndef RT_WIDE_PACKED
+#define RT_WIDE_PACKED 0
+#endif
+constexpr uint32_t LNODE4_STRIDE = 112;    // pl[6][4] | child words[4]: 7 x 16 bytes, 16-byte reads at this stride meet no bank twice
+constexpr uint32_t kKeyMiss = 0xFFFFFFFFu;
+constexpr int32_t kWideNone = -1;
+constexpr uint32_t kWideLdsMaxLeaves = (1u << 14) - 1u, kWideLdsMaxNodes = (1u << 15) / (LNODE4_STRIDE / 16u);
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const floatx4 lds_cfloatx4;
+typedef __attribute__((address_space(3))) const uintx4 lds_cuintx4;
+__device__ __forceinline__ floatx4 lds_float4(uint32_t address) { return *(lds_cfloatx4 *)(uintptr_t)address; }
+__device__ __forceinline__ uintx4 lds_uint4(uint32_t address) { return *(lds_cuintx4 *)(uintptr_t)address; }
+
+__host__ __device__ inline uint32_t wide_word(int32_t ref) {
+    if (ref == REF_NONE) return kKeyMiss;
+    if (ref >= 0) return (uint32_t)ref * (LNODE4_STRIDE / 16u);
+    return 0x8000u | ((uint32_t)(ref & LEAF_INDEX_MASK) << 1) | ((ref & LEAF_SECOND) ? 1u : 0u);
+}
+__device__ __forceinline__ int32_t wide_cur(uint32_t key) { return (int32_t)(int16_t)(uint16_t)key; }
+
+// where a ray finds, in record 0 of the LDS copy, the four planes it meets first and last per axis
+__device__ __forceinline__ PlaneAddr plane_addresses4(const char *lnodes, const RayCtx &r) {
+    const uint32_t ox = r.nx8 << 1, oy = r.ny8 << 1, oz = r.nz8 << 1;   // 0 or 16
+    PlaneAddr a = {lds_address(lnodes + ox), lds_address(lnodes + (ox ^ 16u)), lds_address(lnodes + 32 + oy),
+                   lds_address(lnodes + 32 + (oy ^ 16u)), lds_address(lnodes + 64 + oz), lds_address(lnodes + 64 + (oz ^ 16u))};
+    return a;
+}
+
+// node_test<true> of one child, as a sort key: the bits of the entry distance (clamped to the interval's
+// start) where the box is hit, kKeyMiss where it is not
+__device__ __forceinline__ uint32_t child_entry_bits(float nx, float fx, float ny, float fy, float nz, float fz, const RayCtx &r,
+                                                     float tmin_below, float tmax_above, float limit, bool &hit) {
+    const float tnx = __builtin_fmaf(nx, r.ixf, r.cnx), tfx = __builtin_fmaf(fx, r.ixf, r.cfx);
+    const float tny = __builtin_fmaf(ny, r.iyf, r.cny), tfy = __builtin_fmaf(fy, r.iyf, r.cfy);
+    const float tnz = __builtin_fmaf(nz, r.izf, r.cnz), tfz = __builtin_fmaf(fz, r.izf, r.cfz);
+    const float e_lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float x_hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+    float x_in, e_in;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above), "v"(limit));
+    asm("v_max_f32 %0, %1, %2" : "=v"(e_in) : "v"(e_lo), "v"(tmin_below));
+    hit = !(x_in < e_in);
+    return __float_as_uint(e_in);
+}
+
+__device__ __forceinline__ void key_order(uint32_t &a, uint32_t &b) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+
+// The LDS part of a lane's stack by 32-bit LDS address (entry k at base + k * pitch), so that its reads and
+// writes stay LDS instructions where the spilling path's device-memory accesses are selected beside them.
+typedef __attribute__((address_space(3))) int lds_int;
+struct WideStack {
+    uint32_t base, pitch;
+    int cap;
+    int *spill;
+    int spill_stride;
+};
+__device__ __forceinline__ WideStack wide_stack(const LaneStack &st) {
+    WideStack w = {lds_address(reinterpret_cast<const char *>(st.lds)), (uint32_t)st.stride * 4u, st.cap, st.spill, st.spill_stride};
+    return w;
+}
+__device__ __forceinline__ void wide_put(const WideStack &ws, int k, int32_t v) {
+    if (k < ws.cap) *(lds_int *)(uintptr_t)(ws.base + (uint32_t)k * ws.pitch) = v;
+    else ws.spill[(size_t)(k - ws.cap) * ws.spill_stride] = v;
+}
+__device__ __forceinline__ int32_t wide_get(const WideStack &ws, int k) {
+    int32_t v;
+    if (k < ws.cap) v = *(lds_int *)(uintptr_t)(ws.base + (uint32_t)k * ws.pitch);
+    else v = ws.spill[(size_t)(k - ws.cap) * ws.spill_stride];
+    return v;
+}
+// Pushes the entries that are not kKeyMiss, e3 first (sorted: a miss among them is followed by misses
+// only).  While three more entries fit the LDS part of the stack every entry is written where the next
+// one would go and the count moves on only for a real one; otherwise entry by entry, spilling.
+// (`roomy`, the same for the whole wave: no lane is within three entries of the LDS part's end)
+__device__ __forceinline__ void wide_push(const WideStack &ws, Trav &tv, uint32_t e3, uint32_t e2, uint32_t e1, bool v3, bool v2, bool v1, bool roomy) {
+    if (__builtin_expect(roomy, 1)) {
+        *(lds_int *)(uintptr_t)(ws.base + (uint32_t)tv.sp * ws.pitch) = (int32_t)e3; tv.sp += v3 ? 1 : 0;
+        *(lds_int *)(uintptr_t)(ws.base + (uint32_t)tv.sp * ws.pitch) = (int32_t)e2; tv.sp += v2 ? 1 : 0;
+        *(lds_int *)(uintptr_t)(ws.base + (uint32_t)tv.sp * ws.pitch) = (int32_t)e1; tv.sp += v1 ? 1 : 0;
+    } else {
+        if (v3) { wide_put(ws, tv.sp, (int32_t)e3); ++tv.sp; }
+        if (v2) { wide_put(ws, tv.sp, (int32_t)e2); ++tv.sp; }
+        if (v1) { wide_put(ws, tv.sp, (int32_t)e1); ++tv.sp; }
+    }
+}
+// The next entry of a walk over 16-bit child words.  An entry carries the (truncated, hence lower) entry
+// distance of its box: one whose box starts beyond the best hit found since it was pushed is dropped here,
+// by the comparison that would have kept it off the stack had the hit been known then (node_test).
+#ifndef RT_WIDE_CULL
+#define RT_WIDE_CULL 0
+#endif
+__device__ __forceinline__ int32_t wide_pop16(Trav &tv, const WideStack &ws) {
+    int32_t r = kWideNone;
+#if RT_WIDE_CULL
+    const uint32_t limit = __float_as_uint(tv.bt_above);   // (+inf while there is no hit; never negative)
+    while (tv.sp > 0) {
+        --tv.sp;
+        const uint32_t e = (uint32_t)wide_get(ws, tv.sp);
+        if ((e & 0x7FFF0000u) <= limit) { r = wide_cur(e); break; }
+    }
+#else
+    if (tv.sp > 0) { --tv.sp; r = wide_cur((uint32_t)wide_get(ws, tv.sp)); }
+#endif
+    return r;
+}
+__device__ __forceinline__ int32_t wide_pop32(Trav &tv, const WideStack &ws) {
+    int32_t r = REF_NONE;
+    if (tv.sp > 0) { --tv.sp; r = wide_get(ws, tv.sp); }
+    return r;
+}
+
+// one node of a tree that lives in LDS whole
+__device__ __forceinline__ void node_step4_lds(const PlaneAddr &pa, uint32_t words_address, const RayCtx &r, float tmin_below,
+                                               float tmax_above, const WideStack &st, Trav &tv, bool roomy) {
+    const uint32_t off = (uint32_t)tv.cur << 4;
+    const uintx4 w = lds_uint4(words_address + off);
+    const floatx4 xn = lds_float4(pa.xn + off), xf = lds_float4(pa.xf + off), yn = lds_float4(pa.yn + off), yf = lds_float4(pa.yf + off),
+                  zn = lds_float4(pa.zn + off), zf = lds_float4(pa.zf + off);
+    uint32_t k[4];
+#if RT_WIDE_PACKED
+    // the 24 slab values by packed single-precision fma, two children at a time (the four planes of a
+    // kind arrive in neighbouring registers)
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    floatx2 tnx[2], tfx[2], tny[2], tfy[2], tnz[2], tfz[2];
+    const floatx2 ix = {r.ixf, r.ixf}, iy = {r.iyf, r.iyf}, iz = {r.izf, r.izf};
+    const floatx2 cnx = {r.cnx, r.cnx}, cny = {r.cny, r.cny}, cnz = {r.cnz, r.cnz}, cfx = {r.cfx, r.cfx}, cfy = {r.cfy, r.cfy}, cfz = {r.cfz, r.cfz};
+    tnx[0] = __builtin_elementwise_fma(xn.xy, ix, cnx); tnx[1] = __builtin_elementwise_fma(xn.zw, ix, cnx);
+    tfx[0] = __builtin_elementwise_fma(xf.xy, ix, cfx); tfx[1] = __builtin_elementwise_fma(xf.zw, ix, cfx);
+    tny[0] = __builtin_elementwise_fma(yn.xy, iy, cny); tny[1] = __builtin_elementwise_fma(yn.zw, iy, cny);
+    tfy[0] = __builtin_elementwise_fma(yf.xy, iy, cfy); tfy[1] = __builtin_elementwise_fma(yf.zw, iy, cfy);
+    tnz[0] = __builtin_elementwise_fma(zn.xy, iz, cnz); tnz[1] = __builtin_elementwise_fma(zn.zw, iz, cnz);
+    tfz[0] = __builtin_elementwise_fma(zf.xy, iz, cfz); tfz[1] = __builtin_elementwise_fma(zf.zw, iz, cfz);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float e_lo = __builtin_fmaxf(__builtin_fmaxf(tnx[c >> 1][c & 1], tny[c >> 1][c & 1]), tnz[c >> 1][c & 1]);
+        const float x_hi = __builtin_fminf(__builtin_fminf(tfx[c >> 1][c & 1], tfy[c >> 1][c & 1]), tfz[c >> 1][c & 1]);
+        float x_in, e_in;
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x_in) : "v"(x_hi), "v"(tmax_above), "v"(tv.bt_above));
+        asm("v_max_f32 %0, %1, %2" : "=v"(e_in) : "v"(e_lo), "v"(tmin_below));
+        const uint32_t key = (__float_as_uint(e_in) & 0x7FFF0000u) | w[c];   // (an empty slot's word is all ones)
+        k[c] = !(x_in < e_in) ? key : kKeyMiss;
+    }
+#else
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bool hit;
+        const uint32_t bits = child_entry_bits(xn[c], xf[c], yn[c], yf[c], zn[c], zf[c], r, tmin_below, tmax_above, tv.bt_above, hit);
+        const uint32_t key = (bits & 0x7FFF0000u) | w[c];   // (an empty slot's word is all ones)
+        k[c] = hit ? key : kKeyMiss;
+    }
+#endif
+    key_order(k[0], k[1]); key_order(k[2], k[3]); key_order(k[0], k[2]); key_order(k[1], k[3]); key_order(k[1], k[2]);
+    wide_push(st, tv, k[3], k[2], k[1], k[3] != kKeyMiss, k[2] != kKeyMiss, k[1] != kKeyMiss, roomy);
+    int32_t next = wide_cur(k[0]);
+    if (next == kWideNone) next = wide_pop16(tv, st);
+    tv.cur = next;
+}
+
+// one sphere of a tree that lives in LDS whole (leaf_step_lds<.., true> on a 16-bit reference)
+__device__ __forceinline__ void leaf_step4_lds(const char *lleaves, const RayCtx &r, double tmin, double tmax, const WideStack &st, Trav &tv, bool box_now) {
+    const uint32_t idx = (uint32_t)tv.cur & 0x7FFFu;   // 2 leaf + (second sphere): the primitive's number
+    const char *rec = lleaves + (idx >> 1) * SLEAF_STRIDE;
+    bool reached = true;
+    if (box_now) {
+        double entry;
+        reached = box_test_ordered(rec, r, tmin, tmax, entry);
+    }
+    if (reached) {
+        const double *p = reinterpret_cast<const double *>(rec + 48 + (idx & 1u) * SPRIM_BYTES);
+        double t;
+        if (sphere_root(mk(p[0], p[1], p[2]), p[3], r, tmin, tmax, t)) take_if_closer(t, (int32_t)idx, tv);
+    }
+    tv.cur = wide_pop16(tv, st);
+}
+
+// one node read from device memory: child references are the 32-bit ones of the binary tree, sorted
+// along with the bits of their entry distances
+__device__ __forceinline__ void pair_order(uint32_t &ka, int32_t &ra, uint32_t &kb, int32_t &rb) {
+    const bool swap = kb < ka;
+    const uint32_t k = swap ? kb : ka; const int32_t q = swap ? rb : ra;
+    kb = swap ? ka : kb; rb = swap ? ra : rb;
+    ka = k; ra = q;
+}
+struct PlaneOffsets { uint32_t xn, xf, yn, yf, zn, zf; };   // byte offsets in a DNode4
+__device__ __forceinline__ PlaneOffsets plane_offsets4(const RayCtx &r) {
+    const uint32_t ox = r.nx8 << 1, oy = r.ny8 << 1, oz = r.nz8 << 1;
+    PlaneOffsets o = {ox, ox ^ 16u, 32u + oy, 32u + (oy ^ 16u), 64u + oz, 64u + (oz ^ 16u)};
+    return o;
+}
+__device__ __forceinline__ void node_step4(const DNode4 *nodes4, const PlaneOffsets &po, const RayCtx &r, float tmin_below, float tmax_above,
+                                           const WideStack &st, Trav &tv, bool roomy) {
+    const char *nd = reinterpret_cast<const char *>(nodes4) + (size_t)((uint32_t)tv.cur * (uint32_t)sizeof(DNode4));
+    const uintx4 w = *reinterpret_cast<const uintx4 *>(nd + 96);
+    const floatx4 xn = *reinterpret_cast<const floatx4 *>(nd + po.xn), xf = *reinterpret_cast<const floatx4 *>(nd + po.xf),
+                  yn = *reinterpret_cast<const floatx4 *>(nd + po.yn), yf = *reinterpret_cast<const floatx4 *>(nd + po.yf),
+                  zn = *reinterpret_cast<const floatx4 *>(nd + po.zn), zf = *reinterpret_cast<const floatx4 *>(nd + po.zf);
+    uint32_t k[4];
+    int32_t c4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bool hit;
+        const uint32_t bits = child_entry_bits(xn[c], xf[c], yn[c], yf[c], zn[c], zf[c], r, tmin_below, tmax_above, tv.bt_above, hit);
+        c4[c] = (int32_t)w[c];
+        k[c] = (hit && c4[c] != REF_NONE) ? (bits & 0x7FFFFFFFu) : kKeyMiss;
+    }
+    pair_order(k[0], c4[0], k[1], c4[1]); pair_order(k[2], c4[2], k[3], c4[3]); pair_order(k[0], c4[0], k[2], c4[2]);
+    pair_order(k[1], c4[1], k[3], c4[3]); pair_order(k[1], c4[1], k[2], c4[2]);
+    wide_push(st, tv, (uint32_t)c4[3], (uint32_t)c4[2], (uint32_t)c4[1], k[3] != kKeyMiss, k[2] != kKeyMiss, k[1] != kKeyMiss, roomy);
+    tv.cur = k[0] != kKeyMiss ? c4[0] : wide_pop32(tv, st);
+}
+
+// one sphere read from device memory (leaf_step<.., true> with this walk's stack)
+__device__ __forceinline__ void leaf_step4(const DLeaf *leaves, const DPrim *prims, const RayCtx &r, double tmin, double tmax, const WideStack &st, Trav &tv, bool box_now) {
+    const int32_t ref = tv.cur;
+    const int32_t leaf = ref & LEAF_INDEX_MASK;
+    bool reached = true;
+    if (box_now) {
+        double bx[6], entry;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bx[k] = leaves[leaf].box[k];
+        reached = box_test(bx, r, tmin, tmax, entry);
+    }
+    if (reached) leaf_candidate(prims, 2 * leaf + ((ref & LEAF_SECOND) ? 1 : 0), false, r, tmin, tmax, tv);
+    tv.cur = wide_pop32(tv, st);
+}
+
+// world_closest_voted<.., DEFER = true> over the four-wide tree.  LDS_TREE: nodes and spheres are all
+// in LDS (16-bit child words); otherwise everything is read from device memory.  The stack spills to
+// device memory beyond st.cap entries in either case: a four-wide walk can hold three entries per level.
+template <int LEAF_QUORUM, bool LDS_TREE, bool COUNT_WORK>
+__device__ __forceinline__ bool world_closest_wide(const DScene &sc, const TreeView &tree, const RayCtx &r, double tmin, double tmax,
+                                                   const LaneStack &lane_stack, double &t_out, int &prim_out, uint32_t &work, LaneStats &stats) {
+    const WideStack st = wide_stack(lane_stack);
+#ifndef RT_WIDE_EXTRA
+#define RT_WIDE_EXTRA 2
+#endif
+    constexpr int kExtraNodeSteps = LDS_TREE ? RT_WIDE_EXTRA : 1;
+    constexpr int32_t kNone = LDS_TREE ? kWideNone : REF_NONE;
+    const PlaneAddr pa = plane_addresses4(tree.lnodes, r);
+    const uint32_t words_address = lds_address(tree.lnodes + 96);
+    const PlaneOffsets po = plane_offsets4(r);
+    const float tmin_below = below(tmin);
+    float tmax_above = HUGE_VALF;
+    double closest = tmax;
+    int found = -1;
+    auto begin = [&](uint32_t i, Trav &tv) {
+        const DItem *it = sc.items + i;
+        tv.sp = 0; tv.bp = -1; tv.bt = 0; tv.bt_above = HUGE_VALF; tv.cur = kNone;
+        const int32_t ref = it->ref4;
+        if (!it->has_box) leaf_candidate(sc.prims, 2 * (ref & LEAF_INDEX_MASK), false, r, tmin, closest, tv);
+        else tv.cur = LDS_TREE ? wide_cur(wide_word(ref)) : ref;
+    };
+    auto node = [&](Trav &tv, bool roomy) {
+        if (LDS_TREE) node_step4_lds(pa, words_address, r, tmin_below, tmax_above, st, tv, roomy);
+        else node_step4(sc.nodes4, po, r, tmin_below, tmax_above, st, tv, roomy);
+    };
+    for (uint32_t i = 0; i < sc.n_items; ++i) {
+        Trav tv;
+        begin(i, tv);
+        tmax_above = above(closest);
+        bool exact = false;   // (see world_closest_voted: the first pass tries the spheres without their leaves' box tests)
+        while (tv.cur != kNone) {
+            while (tv.cur != kNone) {
+                const bool at_node = tv.cur >= 0;
+                const int n_node = __popcll(__ballot(at_node));
+                const int n_leaf = __popcll(__ballot(!at_node));
+                if (n_leaf >= LEAF_QUORUM || n_node == 0) {
+                    stats.add(1, (uint32_t)n_leaf);
+                    if (COUNT_WORK) work += 3;
+                    if (!at_node) {
+                        if (LDS_TREE) leaf_step4_lds(tree.lleaves, r, tmin, closest, st, tv, exact);
+                        else leaf_step4(tree.leaves, tree.prims, r, tmin, closest, st, tv, exact);
+                    }
+                } else {
+                    stats.add(0, (uint32_t)n_node);
+                    if (COUNT_WORK) work += 2;
+                    if (at_node) {
+                        // (asked once for the steps that follow: each pushes three entries at most)
+                        const bool roomy = !__any(tv.sp + 3 * (1 + kExtraNodeSteps) > st.cap);
+                        node(tv, roomy);
+#pragma unroll
+                        for (int extra = 0; extra < kExtraNodeSteps; ++extra) {
+                            if (tv.cur >= 0) {
+                                stats.add(0, (uint32_t)__popcll(__ballot(true)));
+                                if (COUNT_WORK) work += 2;
+                                node(tv, roomy);
+                            }
+                        }
+                    }
+                }
+            }
+            if (exact) break;
+            bool again = false;
+            if (tv.bp >= 0) again = sc.recheck_all || !leaf_box_reached<LDS_TREE>(tree, tv.bp >> 1, r, tmin, closest);
+            if (!__any(again)) break;
+            exact = true;
+            if (again) begin(i, tv);
         }
         if (tv.bp >= 0) { closest = tv.bt; found = tv.bp; }
     }

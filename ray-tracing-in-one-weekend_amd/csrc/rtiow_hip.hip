@@ -194,7 +194,10 @@ constexpr uint32_t kSamplesPerLaunch = 4096;            // samples a launch may 
 // adding to the image each tile records how much work it was (tile_cost).
 // DEFER: the walk postpones the box tests of static-sphere leaves (world_closest_voted); chosen
 // per scene.
-template <class AccT, bool LDS_TREE, int WAVES, bool COSTING, bool DEFER>
+// WIDE (with DEFER): the walk runs over the four-wide tree (world_closest_wide): LDS_TREE then means the
+// DNode4 records and the spheres are in LDS; without it everything is read from device memory and LDS
+// holds the stacks only.
+template <class AccT, bool LDS_TREE, int WAVES, bool COSTING, bool DEFER, bool WIDE = false>
 __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_arg, uint32_t nx, uint32_t ny, uint32_t s_begin,
                                                        uint32_t s_end, uint32_t max_depth, double t_min, uint64_t seed,
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
@@ -221,8 +224,14 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                           spill ? spill + (size_t)blockIdx.x * kRenderBlock + tid : nullptr, (int)(gridDim.x * kRenderBlock)};
     TreeView tree = {sc.nodes, sc.leaves, sc.prims, nullptr, nullptr, (int32_t)n_lnodes};
     {
-        char *lnodes = ltree, *lleaves = ltree + (((size_t)n_lnodes * LNODE_STRIDE + 7) & ~(size_t)7);
-        for (uint32_t i = tid; i < n_lnodes * 15u; i += kRenderBlock) {   // 15 words of a node record are copied
+        char *lnodes = ltree, *lleaves = ltree + (((size_t)n_lnodes * (WIDE ? LNODE4_STRIDE : LNODE_STRIDE) + 7) & ~(size_t)7);
+        for (uint32_t i = tid; WIDE && i < n_lnodes * 28u; i += kRenderBlock) {   // 24 planes and the four child words (see wide_word)
+            const uint32_t n = i / 28u, w = i % 28u;
+            uint32_t v = reinterpret_cast<const uint32_t *>(sc.nodes4 + n)[w];
+            if (w >= 24u) v = wide_word((int32_t)v);
+            reinterpret_cast<uint32_t *>(lnodes + (size_t)n * LNODE4_STRIDE)[w] = v;
+        }
+        for (uint32_t i = tid; !WIDE && i < n_lnodes * 15u; i += kRenderBlock) {   // 15 words of a node record are copied
             const uint32_t n = i / 15u, w = i % 15u;
             uint32_t v = reinterpret_cast<const uint32_t *>(sc.nodes + n)[w];
             // a tree that is in LDS whole refers to its nodes by the byte offset of their records
@@ -402,7 +411,9 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                 int prim;
                 ++nrays;
                 if (COSTING) work += 8;   // claiming, set-up and shading of one segment, in node-step units
-                const bool hit_something = world_closest_voted<(LDS_TREE ? (DEFER ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_PAIRS) : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats);
+                bool hit_something;
+                if (WIDE) hit_something = world_closest_wide<(LDS_TREE ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats);
+                else hit_something = world_closest_voted<(LDS_TREE ? (DEFER ? RT_LEAF_QUORUM : RT_LEAF_QUORUM_PAIRS) : RT_LEAF_QUORUM_LARGE), LDS_TREE, COSTING, DEFER>(sc, tree, ctx, t_min, DBL_MAX, st, t, prim, work, lane_stats);
 #ifdef RT_LANE_STATS
                 clk2 = clock64();
 #endif
@@ -575,6 +586,7 @@ struct rt_scene {
     int device = 0;
     DScene d{};
     dev_buf<DNode> nodes;
+    dev_buf<DNode4> nodes4;
     dev_buf<DLeaf> leaves;
     dev_buf<DPrim> prims;
     dev_buf<DItem> items;
@@ -600,6 +612,7 @@ struct rt_scene {
     // shape of the render kernel for this scene (see k_render)
     bool render_lds_tree = false;
     bool render_defer = false;               // the kernel variant that postpones leaf-box tests
+    bool render_wide = false;                // ... walking the four-wide tree
     int render_waves = kWavesMin;            // per SIMD
     uint32_t render_lnodes = 0, render_lleaves = 0, render_stack_cap = 0;
     size_t render_lds_bytes = 0;
@@ -941,6 +954,57 @@ struct flattener {
         if (any) ++max_depth;
     }
 
+    // ---- four-wide tree ------------------------------------------------------------------
+    // Folds the binary tree into nodes of up to four children: a node starts with the two children of
+    // its binary node and, while it has room, replaces the child of largest surface area that is
+    // itself a node by that node's two children.  The boxes are the binary tree's own child boxes
+    // (single precision, already moved and rounded outward): each still contains every leaf box
+    // below it, which is all the conservative walk asks of an inner box.
+    std::vector<DNode4> nodes4;
+    uint32_t depth4 = 0;
+    static float area4(const float *b) {
+        const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+        const float a = dx * dy + dy * dz + dz * dx;
+        return a >= 0 ? a : 0;   // (NaN or inverted: no preference)
+    }
+    int32_t collapse(int32_t b, uint32_t depth) {
+        const size_t me = nodes4.size();
+        nodes4.emplace_back();
+        if (depth + 1 > depth4) depth4 = depth + 1;
+        struct slot { int32_t ref; float box[6]; } s[4];
+        int n = 2;
+        for (int c = 0; c < 2; ++c) { s[c].ref = nodes[(size_t)b].child[c]; memcpy(s[c].box, nodes[(size_t)b].bx[c], sizeof s[c].box); }
+        while (n < 4) {
+            int best = -1;
+            float best_area = -1;
+            for (int i = 0; i < n; ++i)
+                if (s[i].ref >= 0 && area4(s[i].box) > best_area) { best = i; best_area = area4(s[i].box); }
+            if (best < 0) break;
+            const DNode &c = nodes[(size_t)s[best].ref];
+            s[best].ref = c.child[0]; memcpy(s[best].box, c.bx[0], sizeof s[best].box);
+            s[n].ref = c.child[1]; memcpy(s[n].box, c.bx[1], sizeof s[n].box);
+            ++n;
+        }
+        DNode4 out;
+        memset(&out, 0, sizeof out);
+        for (int i = 0; i < 4; ++i) {
+            out.child[i] = REF_NONE;
+            for (int k = 0; k < 6; ++k) out.pl[k][i] = (k & 1) ? -HUGE_VALF : HUGE_VALF;   // an inverted box
+        }
+        for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < 6; ++k) out.pl[k][i] = s[i].box[k];
+            out.child[i] = s[i].ref >= 0 ? collapse(s[i].ref, depth + 1) : s[i].ref;
+        }
+        nodes4[me] = out;
+        return (int32_t)me;
+    }
+    void collapse4(std::vector<DItem> &items) {
+        nodes4.clear();
+        nodes4.reserve(nodes.size() / 2 + 1);
+        depth4 = 0;
+        for (DItem &it : items) it.ref4 = (it.has_box && it.ref >= 0) ? collapse(it.ref, 0) : it.ref;
+    }
+
     // Renumbers the nodes so that the k nearest to the roots, breadth-first, come first (the
     // part of a large tree the render kernel keeps in LDS); the others keep their order.
     void stage_top_levels(size_t k, std::vector<DItem> &items) {
@@ -1156,6 +1220,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             di.ref = fl.leaf_of(it.index, it.index, unbounded, safe);
         }
         if (fl.error) return fail(RT_E_UNSUPPORTED, "%s", fl.error);
+        di.ref4 = di.ref;
         items.push_back(di);
     }
 
@@ -1182,17 +1247,29 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     }
+    // RTIOW_WIDE=1: scenes without moving spheres walk a four-wide tree instead of the binary one.  Half
+    // the steps per walk, but a step costs more than two of the binary walk's: measured 3-4 % slower on
+    // the 485-sphere scene (tree in LDS) and on 10^6 spheres (tree in device memory), so it is not the
+    // default; the test suite holds it to the binary walk's frames bit for bit.
+    const char *wide_env = getenv("RTIOW_WIDE");
+    const bool wide = static_scene && wide_env && atoi(wide_env) == 1;
+    if (wide) fl.collapse4(items);
     // shape of the render kernel: everything in LDS when it fits, else the top levels only
-    const uint32_t stack_depth = fl.max_depth + 2;
+    // (a binary walk holds one stack entry per level; a four-wide one up to three, and its pushes write three entries ahead)
+    const uint32_t stack_depth = fl.max_depth + 2, stack_depth4 = 3 * fl.depth4 + 4;
     size_t spill_ints = 0;
     {
         // per wave: the sums of its open tiles, 24 bytes a pixel -- four 4x4 tiles or one 8x8 tile beside a
         // tree that fills LDS, twice that when only the top of the tree is there
         constexpr size_t kSumsLdsTree = 1536, kSumsLargeTree = 3072;
         size_t sums = kSumsLdsTree;
+        const size_t leaf_bytes = fl.leaf_boxes.size() * (static_scene ? SLEAF_STRIDE : LLEAF_STRIDE);
         auto whole_tree = [&](int waves) {
-            return kHeadLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) +
-                   fl.leaf_boxes.size() * (static_scene ? SLEAF_STRIDE : LLEAF_STRIDE);
+            return kHeadLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) + leaf_bytes;
+        };
+        // the four-wide tree whole in LDS, with `cap` stack entries per lane there
+        auto whole_tree4 = [&](int waves, uint32_t cap) {
+            return kHeadLds + 4 * waves * sums + (size_t)cap * 256 * waves * sizeof(int) + ((fl.nodes4.size() * LNODE4_STRIDE + 15) & ~(size_t)15) + leaf_bytes;
         };
         const char *force_waves = getenv("RTIOW_RENDER_WAVES");   // "3" keeps the 768-thread shape (tests)
         const int waves_fit = whole_tree(kWavesMax) <= kLdsBudget && !(force_waves && atoi(force_waves) == kWavesMin) ? kWavesMax : kWavesMin;
@@ -1201,13 +1278,42 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         // RTIOW_RENDER_STACK_CAP=c its LDS stack entries, so that small scenes can exercise
         // the staged walk and the spilling stack in tests.
         const char *force_nodes = getenv("RTIOW_RENDER_LDS_NODES"), *force_cap = getenv("RTIOW_RENDER_STACK_CAP");
-        if (whole <= kLdsBudget && !force_nodes) {
+        // LDS stack entries of a four-wide walk: its worst case is rarely approached, so twelve entries (or
+        // what the tree leaves room for, at least eight) stay in LDS and deeper ones spill
+        const int waves4 = force_waves && atoi(force_waves) == kWavesMin ? kWavesMin : kWavesMax;
+        uint32_t cap4 = std::min<uint32_t>(stack_depth4, 12);
+        if (const char *e = getenv("RTIOW_WIDE_STACK_CAP")) cap4 = std::min<uint32_t>(stack_depth4, (uint32_t)std::max(4, atoi(e)));
+        if (force_cap) cap4 = std::min<uint32_t>(cap4, (uint32_t)std::max(4, atoi(force_cap)));
+        const bool wide_in_lds = wide && !force_nodes && fl.nodes4.size() <= kWideLdsMaxNodes && fl.leaf_boxes.size() <= kWideLdsMaxLeaves &&
+                                 whole_tree4(waves4, cap4) <= kLdsBudget;
+        if (wide_in_lds) {
+            s->render_wide = true;
+            s->render_lds_tree = true;
+            s->render_waves = waves4;
+            s->render_lnodes = (uint32_t)fl.nodes4.size();
+            s->render_lleaves = (uint32_t)fl.leaf_boxes.size();
+            s->render_stack_cap = cap4;
+            s->render_lds_bytes = whole_tree4(waves4, cap4);
+            if (stack_depth4 > cap4) spill_ints = (size_t)(stack_depth4 - cap4) * s->n_cus * 256 * waves4;
+        } else if (whole <= kLdsBudget && !force_nodes) {
             s->render_lds_tree = true;
             s->render_waves = waves_fit;
             s->render_lnodes = (uint32_t)fl.nodes.size();
             s->render_lleaves = (uint32_t)fl.leaf_boxes.size();
             s->render_stack_cap = stack_depth;
             s->render_lds_bytes = whole;
+        } else if (wide) {
+            // the four-wide tree in device memory: LDS holds the stacks
+            sums = kSumsLargeTree;
+            uint32_t cap = std::min<uint32_t>(stack_depth4, 16);
+            if (const char *e = getenv("RTIOW_WIDE_STACK_CAP")) cap = std::min<uint32_t>(stack_depth4, (uint32_t)std::max(4, atoi(e)));
+            if (force_cap) cap = std::min<uint32_t>(cap, (uint32_t)std::max(4, atoi(force_cap)));
+            s->render_wide = true;
+            s->render_waves = kWavesMax;
+            s->render_lnodes = 0;
+            s->render_stack_cap = cap;
+            s->render_lds_bytes = kHeadLds + 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
+            if (stack_depth4 > cap) spill_ints = (size_t)(stack_depth4 - cap) * s->n_cus * 256 * kWavesMax;
         } else {
             sums = kSumsLargeTree;
             uint32_t cap = std::min<uint32_t>(stack_depth, kSpillStackCap);
@@ -1266,6 +1372,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     }
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
+    if (e == hipSuccess && s->render_wide) e = s->nodes4.upload(fl.nodes4.data(), fl.nodes4.size());
     if (e == hipSuccess) e = s->leaves.upload(fl.leaf_boxes.data(), fl.leaf_boxes.size());
     if (e == hipSuccess) e = s->prims.upload(fl.prims.data(), fl.prims.size());
     if (e == hipSuccess) e = s->items.upload(items.data(), items.size());
@@ -1278,26 +1385,26 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->spill_ints = spill_ints;
     lap("upload");
     // the kernels with per-lane stacks may ask for more dynamic LDS than the default 64 KiB limit
-    const void *kernels[19] = {
+    const void *kernels[28] = {
         reinterpret_cast<const void *>(&k_trace_batch),
-#define RT_SHAPES(D)                                                                \
-    reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, false, D>),    \
-    reinterpret_cast<const void *>(&k_render<double, true, kWavesMax, false, D>),   \
-    reinterpret_cast<const void *>(&k_render<float, true, kWavesMin, false, D>),    \
-    reinterpret_cast<const void *>(&k_render<double, true, kWavesMin, false, D>),   \
-    reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, false, D>),   \
-    reinterpret_cast<const void *>(&k_render<double, false, kWavesMax, false, D>),  \
-    reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, true, D>),     \
-    reinterpret_cast<const void *>(&k_render<float, true, kWavesMin, true, D>),     \
-    reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, true, D>)
-        RT_SHAPES(false), RT_SHAPES(true)
+#define RT_SHAPES(D, W)                                                                \
+    reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, false, D, W>),    \
+    reinterpret_cast<const void *>(&k_render<double, true, kWavesMax, false, D, W>),   \
+    reinterpret_cast<const void *>(&k_render<float, true, kWavesMin, false, D, W>),    \
+    reinterpret_cast<const void *>(&k_render<double, true, kWavesMin, false, D, W>),   \
+    reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, false, D, W>),   \
+    reinterpret_cast<const void *>(&k_render<double, false, kWavesMax, false, D, W>),  \
+    reinterpret_cast<const void *>(&k_render<float, true, kWavesMax, true, D, W>),     \
+    reinterpret_cast<const void *>(&k_render<float, true, kWavesMin, true, D, W>),     \
+    reinterpret_cast<const void *>(&k_render<float, false, kWavesMax, true, D, W>)
+        RT_SHAPES(false, false), RT_SHAPES(true, false), RT_SHAPES(true, true)
 #undef RT_SHAPES
     };
     for (const void *k : kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "scene upload: %s", hipGetErrorString(e));
     lap("kernel attributes");
-    s->d.nodes = s->nodes.p; s->d.leaves = s->leaves.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
+    s->d.nodes = s->nodes.p; s->d.nodes4 = s->render_wide ? s->nodes4.p : nullptr; s->d.leaves = s->leaves.p; s->d.prims = s->prims.p; s->d.items = s->items.p;
     s->d.mats = s->mats.p; s->d.texs = s->texs.p; s->d.ranfloat = s->ranfloat.p; s->d.perm = s->perm.p;
     s->d.n_items = (uint32_t)items.size();
     s->d.stack_depth = stack_depth;
@@ -1377,7 +1484,8 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render kernel: %s, %u nodes and %u leaves in LDS, "
                         "%u stack entries in LDS, %zu B of LDS (budget %zu), %zu B of spill, leaf boxes tested %s\n",
                 fl.nodes.size(), (size_t)desc->n_prims, fl.max_depth, reference_layout ? "reference" : "re-clustered",
-                s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
+                s->render_wide ? (s->render_lds_tree ? (s->render_waves == kWavesMax ? "four-wide tree whole in LDS, 1024 threads" : "four-wide tree whole in LDS, 768 threads") : "four-wide tree in device memory, 1024 threads")
+                               : s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
                 s->render_lnodes, s->render_lleaves,
                 s->render_stack_cap, s->render_lds_bytes, kLdsBudget, spill_ints * sizeof(int), s->render_defer ? "for the winning leaf" : "up front");
     if (verbose) fprintf(stderr, "rtiow: scene created in %.3f s (%.3f s of it after the layout: kernel shape, top levels, upload)\n", seconds_since(t_start), seconds_since(t_start) - t_layout);
@@ -1576,7 +1684,9 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
         if (std::sqrt(d2) + std::fabs(camera->lens_radius) * 2 <= scene->far_free_radius) dsc.far.k = 0;
     }
 #define RT_LAUNCH(T, L, W, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
-    hipLaunchKernelGGL((k_render<T, L, W, C, D>), grid, block, scene->render_lds_bytes, stream, dsc, cam, pr->nx, pr->ny,   \
+    RT_LAUNCH_WIDTH(T, L, W, C, D, false, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)
+#define RT_LAUNCH_WIDTH(T, L, W, C, D, X, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
+    hipLaunchKernelGGL((k_render<T, L, W, C, D, X>), grid, block, scene->render_lds_bytes, stream, dsc, cam, pr->nx, pr->ny,   \
                        s_from, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                           \
                        scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT, \
                        scene->render_sums_per_wave)
@@ -1588,7 +1698,11 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     } while (0)
 #define RT_LAUNCH_SHAPE(T, C, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                        \
     do {                                                                                                                  \
-        if (scene->render_defer) RT_LAUNCH_TREE(T, C, true, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                             \
+        if (scene->render_wide) {                                                                                         \
+            if (!scene->render_lds_tree) RT_LAUNCH_WIDTH(T, false, kWavesMax, C, true, true, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \
+            else if (scene->render_waves == kWavesMax) RT_LAUNCH_WIDTH(T, true, kWavesMax, C, true, true, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);  \
+            else RT_LAUNCH_WIDTH(T, true, kWavesMin, C, true, true, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                                       \
+        } else if (scene->render_defer) RT_LAUNCH_TREE(T, C, true, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                             \
         else RT_LAUNCH_TREE(T, C, false, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);                                              \
     } while (0)
     uint32_t s_from = pr->sample_begin;
@@ -1614,6 +1728,7 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     }
 #undef RT_LAUNCH_SHAPE
 #undef RT_LAUNCH_TREE
+#undef RT_LAUNCH_WIDTH
 #undef RT_LAUNCH
     HIP_TRY(hipGetLastError());
     return RT_OK;

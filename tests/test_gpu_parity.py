@@ -610,6 +610,60 @@ def test_postponed_leaf_box_tests_change_nothing(rt, orc, scene, monkeypatch):
     np.testing.assert_allclose(frames[0][0], exp, rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("scene", ["book1", "stress4096", "ties", "lists_static"])
+def test_four_wide_walk_changes_nothing(rt, orc, scene, monkeypatch, tmp_path, capfd):
+    # RTIOW_WIDE=1: scenes without moving spheres walk a tree of four-child nodes (every other level of
+    # the binary tree folded away).  Same candidates, same tie rule (bvh_node.cpp:57-61 -> the later
+    # primitive among equals): the frame of the binary walk, to the bit, with the tree in LDS, with the
+    # tree in device memory, with a stack that spills after four entries, with every hit sent through the
+    # second, exact walk, and on the reference's own tree layout; and the oracle's frame.
+    if scene == "lists_static":      # object_lists below bvh nodes, bare spheres beside them, no moving sphere
+        rng = np.random.default_rng(3)
+        path = tmp_path / "ls.recipe"
+        while True:
+            _random_recipe(rng, path, moving=False)
+            if "list_begin" in path.read_text() and path.read_text().count("sphere") > 40:
+                break
+        scene_path = str(path)
+        cam15 = np.array([3.0, 2.0, 3.0, 0, 0, 0, 0, 1, 0, 40, 2.0, 0.0, 4.0, 0, 1], dtype=np.float64)
+        scale = float(np.abs(np.array([[float(v) for v in l.split()[2:5]] for l in path.read_text().splitlines() if l.startswith("sphere")])).max())
+        cam15[[0, 1, 2, 12]] *= max(scale, 1e-3)
+    else:
+        scene_path = recipe(scene)
+        cam15 = np.array(golden("frames")["camera"])
+        cam15[10] = 2.0
+    frames = []
+    cases = [{}, {"RTIOW_WIDE": "1"}, {"RTIOW_WIDE": "1", "RTIOW_RECHECK_ALL_LEAVES": "1"}, {"RTIOW_WIDE": "1", "RTIOW_WIDE_STACK_CAP": "4"},
+             {"RTIOW_WIDE": "1", "RTIOW_RENDER_LDS_NODES": "0"}, {"RTIOW_WIDE": "1", "RTIOW_RENDER_LDS_NODES": "0", "RTIOW_WIDE_STACK_CAP": "4", "RTIOW_RECHECK_ALL_LEAVES": "1"},
+             {"RTIOW_WIDE": "1", "RTIOW_TREE": "reference"}, {"RTIOW_WIDE": "1", "RTIOW_RENDER_WAVES": "3"}]
+    monkeypatch.setenv("RTIOW_VERBOSE", "1")
+    for env in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        capfd.readouterr()
+        w = rt.World(scene_path)
+        said = capfd.readouterr().err
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        if env:     # the shape asked for is the shape in use
+            in_lds = "RTIOW_RENDER_LDS_NODES" not in env and scene != "stress4096"     # (4096 spheres do not fit)
+            assert ("four-wide tree whole in LDS" if in_lds else "four-wide tree in device memory") in said, said
+            assert ("768 threads" in said) == ("RTIOW_RENDER_WAVES" in env and in_lds)
+        else:
+            assert "four-wide" not in said
+        try:
+            frames.append(w.render(rt.camera(cam15), 72, 36, 0, 5, 33))
+            frames.append(w.render(rt.camera(cam15), 72, 36, 0, 40, 33))     # deep enough for the costing pass and ordered tiles
+        finally:
+            w.close()
+    exp, counters = orc.Scene(scene_path).render(cam15, 72, 36, 0, 5, 33, orc.ORC_RNG_STREAM)
+    for k, (f, st) in enumerate(frames):
+        assert np.array_equal(f, frames[k % 2][0]), cases[k // 2]
+        assert st.rays == frames[k % 2][1].rays, cases[k // 2]
+    assert frames[0][1].rays == counters.rays
+    np.testing.assert_allclose(frames[0][0], exp, rtol=1e-11, atol=1e-13)
+
+
 @pytest.mark.parametrize("scene", ["book1", "stress4096", "ties"])
 def test_grazing_rays_reach_their_spheres(rt, orc, scene):
     # In a scene without moving spheres every sphere sits behind a box of its own (single precision,

@@ -71,6 +71,9 @@ KERNEL_U32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
 KERNEL_U32(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL_U32(k_lshl_add, "v_lshl_add_u32 %0, %0, 9, %1")
 KERNEL_U32(k_cvt_f64_u32, "v_cvt_f32_u32 %0, %0")
+KERNEL_U32(k_min_u32, "v_min_u32 %0, %0, %1")
+KERNEL_U32(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL_U32(k_min3_f32, "v_min3_f32 %0, %0, %1, %2")
 
 __global__ void k_cmp_f64(double *out, long long *clk) {
     double a = 1.000001 + threadIdx.x * 1e-9, b = 0.999999;
@@ -90,14 +93,15 @@ __global__ void k_lds_read(double *out, long long *clk) {
     for (int i = threadIdx.x; i < 8192; i += blockDim.x) buf[i] = i;
     __syncthreads();
     // 120-byte record stride, as the render kernel's node records
-    unsigned addr = (unsigned)(size_t)buf + (threadIdx.x * 37u % 500u) * 120u;
+    unsigned addr = (unsigned)(size_t)buf + (threadIdx.x * 37u % 500u) * (BYTES == 16 ? 112u : 120u);
     double r[16];
     for (int i = 0; i < 16; ++i) r[i] = 0;
     long long t0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (BYTES == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[i]) : "v"(addr), "n"(i * 8));
+            if (BYTES == 16) { __attribute__((ext_vector_type(4))) unsigned q; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"((i & 3) * 16)); r[i] = q.x + q.w; }
+            else if (BYTES == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[i]) : "v"(addr), "n"(i * 8));
             else { unsigned x; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x) : "v"(addr), "n"(i * 8)); r[i] = x; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)");
@@ -120,7 +124,8 @@ int main() {
         {"v_fma_f32", k_fma_f32}, {"v_max3_f32", k_max3_f32}, {"v_max_f32", k_max_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
         {"v_add_u32", k_add_u32}, {"v_xor_b32", k_xor_b32}, {"v_lshlrev_b32", k_lshl_b32}, {"v_alignbit_b32", k_alignbit},
         {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mul_u32_u24", k_mul_u24}, {"v_cndmask_b32", k_cndmask},
-        {"ds_read_b64", k_lds_read<8>}, {"ds_read_b32", k_lds_read<4>},
+        {"v_min_u32", k_min_u32}, {"v_and_or_b32", k_and_or}, {"v_min3_f32", k_min3_f32},
+        {"ds_read_b64", k_lds_read<8>}, {"ds_read_b32", k_lds_read<4>}, {"ds_read_b128", k_lds_read<16>},
     };
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
