@@ -156,6 +156,23 @@ int rt_camera_batch(int device, const rt_camera *camera, const double *st, const
 int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
               void *accum_dev, void *stream, rt_stats *stats);
 
+/* The pixel/sample loop of main.cpp:126-141 on several GPUs of one node, split by sample index
+ * as the reference's README proposes for threads (README.md:21-23: every worker renders the
+ * whole image with its own samples, the results are merged).  scenes[g] is the same world
+ * uploaded to the g-th GPU of the caller's choice (rt_scene_create with that device); scene g
+ * renders the samples [b + g S / n, b + (g + 1) S / n) of every pixel, b = sample_begin and
+ * S = sample_end - sample_begin, on its own host thread and stream.  The per-GPU sums are
+ * added into the first scene's GPU with one RCCL reduction (ncclReduce, sum, over xGMI) and
+ * copied to accum_host (nx*ny*3 sums of params->accum_type; what it held before is
+ * overwritten).  The random streams are keyed by (pixel, global sample index): the set of
+ * paths is the one a single GPU traces for the whole range.  Scenes that share a GPU render
+ * one after the other into that GPU's buffer; with a single GPU in the list no collective
+ * is run and RCCL is not loaded (librccl.so.1 is opened on first use).
+ * stats: paths and rays summed over the scenes, kernel_ms the largest per-GPU render time;
+ * may be NULL. */
+int rt_render_multi(rt_scene *const *scenes, uint32_t n_scenes, const rt_camera *camera,
+                    const rt_render_params *params, void *accum_host, rt_stats *stats);
+
 /* rt_render for callers that cannot allocate.  It has no counterpart in the reference: it
  * is for code under HIP graph capture, tight serving loops and harnesses that forbid
  * hipMalloc.  Same arguments and same image as rt_render, bit for bit, without the

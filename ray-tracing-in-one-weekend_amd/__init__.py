@@ -73,7 +73,7 @@ class rt_scene_desc(ctypes.Structure):
 # every symbol include/rtiow_hip.h declares
 HIP_SYMBOLS = ["rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_trace_batch",
                "rt_aabb_hit_batch", "rt_texture_batch", "rt_scatter_batch", "rt_camera_batch", "rt_render",
-               "rt_render_noalloc", "rt_render_host", "rt_resolve"]
+               "rt_render_noalloc", "rt_render_host", "rt_render_multi", "rt_resolve"]
 
 _hip = None
 _host = None
@@ -123,6 +123,7 @@ def hip():
         lib.rt_render.argtypes = [vp, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, vp, ctypes.POINTER(rt_stats)]
         lib.rt_render_noalloc.argtypes = [vp, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, vp]
         lib.rt_render_host.argtypes = [vp, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, ctypes.POINTER(rt_stats)]
+        lib.rt_render_multi.argtypes = [ctypes.POINTER(vp), u32, ctypes.POINTER(rt_camera), ctypes.POINTER(rt_render_params), vp, ctypes.POINTER(rt_stats)]
         lib.rt_resolve.argtypes = [ctypes.c_int, vp, sz, u32, vp, vp]
         lib.rt_scene_destroy.argtypes = [vp]
         _hip = lib
@@ -255,6 +256,17 @@ def camera_batch(cam, st, tape, device=-1):
     if rc != RT_E_TAPE:
         _check(rc, "rt_camera_batch")
     return out, used
+
+
+def render_multi(worlds, cam, nx, ny, s_begin, s_end, seed, accum=RT_ACCUM_F32, max_depth=50, t_min=0.001):
+    """rt_render_multi: the frame's samples [s_begin, s_end) split over the GPUs that hold `worlds` (the same
+    world uploaded to each), the sums merged on the first one and returned, shape (ny, nx, 3), plus stats."""
+    p = rt_render_params(nx, ny, s_begin, s_end, max_depth, accum, t_min, seed)
+    out = np.zeros((ny, nx, 3), np.float64 if accum == RT_ACCUM_F64 else np.float32)
+    stats = rt_stats()
+    handles = (ctypes.c_void_p * len(worlds))(*[w.scene for w in worlds])
+    _check(hip().rt_render_multi(handles, len(worlds), ctypes.byref(cam), ctypes.byref(p), _ptr(out), ctypes.byref(stats)), "rt_render_multi")
+    return out, stats
 
 
 class World:

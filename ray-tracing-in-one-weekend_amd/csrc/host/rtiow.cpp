@@ -15,6 +15,8 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <exception>
 
 namespace rtiow {
 
@@ -685,8 +687,51 @@ frame render(device_scene const& scene, camera const& cam, render_options const&
 }
 
 frame render(object const& world, camera const& cam, render_options const& opt) {
+    if (!opt.devices.empty()) return render(upload(world, opt.devices), cam, opt);
     device_scene scene(world, opt.device);
     return render(scene, cam, opt);
+}
+
+std::vector<std::unique_ptr<device_scene>> upload(object const& world, std::vector<int> const& devices) {
+    std::vector<std::unique_ptr<device_scene>> scenes(devices.size());
+    std::vector<std::exception_ptr> errors(devices.size());
+    std::vector<char const*> thrown(devices.size(), nullptr);     // (the scene API throws string literals, as the reference does)
+    auto one = [&](size_t k) {
+        try {
+            scenes[k] = std::make_unique<device_scene>(world, devices[k]);
+        } catch (char const* e) {
+            thrown[k] = e;
+        } catch (...) {
+            errors[k] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t k = 1; k < devices.size(); ++k) threads.emplace_back(one, k);
+    if (!devices.empty()) one(0);
+    for (std::thread& t : threads) t.join();
+    for (size_t k = 0; k < devices.size(); ++k) {
+        if (thrown[k]) throw thrown[k];
+        if (errors[k]) std::rethrow_exception(errors[k]);
+    }
+    return scenes;
+}
+
+frame render(std::vector<std::unique_ptr<device_scene>> const& scenes, camera const& cam, render_options const& opt) {
+    frame f;
+    f.nx = opt.nx; f.ny = opt.ny; f.ns = opt.ns;
+    f.sums.assign((size_t)opt.nx * opt.ny * 3, 0.0f);
+    rt_camera const c = cam.describe();
+    rt_render_params p{};
+    p.nx = (uint32_t)opt.nx; p.ny = (uint32_t)opt.ny;
+    p.sample_begin = 0; p.sample_end = (uint32_t)opt.ns;
+    p.max_depth = (uint32_t)opt.max_depth;
+    p.accum_type = RT_ACCUM_F32;
+    p.t_min = opt.t_min;
+    p.seed = opt.seed;
+    std::vector<rt_scene*> handles;
+    for (auto const& s : scenes) handles.push_back(s ? s->get() : nullptr);
+    if (rt_render_multi(handles.data(), (uint32_t)handles.size(), &c, &p, f.sums.data(), &f.stats)) device_failure("render");
+    return f;
 }
 
 colour frame::pixel(int i, int row) const {

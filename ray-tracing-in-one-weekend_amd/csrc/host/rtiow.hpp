@@ -318,6 +318,9 @@ struct render_options {
     double t_min = 0.001;              // main.cpp:23
     uint64_t seed = 0;
     int device = -1;                   // -1: the calling thread's current HIP device
+    // Several GPUs: the frame's ns samples are split between them by sample index (README.md:21-23), each
+    // renders its share of every pixel, and the sums are merged with one RCCL reduction.  Empty: `device`.
+    std::vector<int> devices;
 };
 
 struct frame {
@@ -330,9 +333,13 @@ struct frame {
     void write_png(std::FILE* out) const;          // the same values as an 8-bit RGB PNG
 };
 
-// The pixel/sample loop of main.cpp:126-141 on one GPU.
+// The pixel/sample loop of main.cpp:126-141 on one GPU, or on opt.devices.
 frame render(object const& world, camera const& cam, render_options const& opt);
 frame render(device_scene const& scene, camera const& cam, render_options const& opt);
+// ... on the GPUs that hold `scenes` (the same world uploaded to each: upload()), sample ranges in list order
+frame render(std::vector<std::unique_ptr<device_scene>> const& scenes, camera const& cam, render_options const& opt);
+// the world on each of `devices`, uploaded by one host thread per device
+std::vector<std::unique_ptr<device_scene>> upload(object const& world, std::vector<int> const& devices);
 
 // Scene builders of main.cpp:52-99.  The argument evaluation order that the reference
 // leaves to the compiler (main.cpp:89) is fixed here: albedo red, green, blue, then

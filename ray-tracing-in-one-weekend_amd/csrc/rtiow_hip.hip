@@ -7,6 +7,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is opened on first use (rccl_api)
+#include <dlfcn.h>
 
 #include <cfloat>
 #include <chrono>
@@ -19,6 +21,8 @@
 #include <cstring>
 #include <array>
 #include <future>
+#include <map>
+#include <string>
 #include <thread>
 #include <memory>
 #include <mutex>
@@ -1834,6 +1838,168 @@ int rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_par
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(accum_host, d.p, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
+}
+
+// ---- several GPUs ------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// RCCL, opened when a frame first needs a collective: single-GPU callers never load it.
+struct rccl_api {
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+    std::string why;
+    rccl_api() {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { why = dlerror() ? dlerror() : "librccl.so.1 not found"; return; }
+        comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(h, "ncclCommInitAll"));
+        reduce = reinterpret_cast<decltype(reduce)>(dlsym(h, "ncclReduce"));
+        error_string = reinterpret_cast<decltype(error_string)>(dlsym(h, "ncclGetErrorString"));
+        ok = comm_init_all && reduce && error_string;
+        if (!ok) why = "librccl lacks ncclCommInitAll / ncclReduce / ncclGetErrorString";
+    }
+};
+rccl_api &rccl() { static rccl_api api; return api; }
+
+// One communicator per rank for a list of devices, made once per list and kept until the process ends
+// (ncclCommInitAll takes seconds; a renderer calls with the same list frame after frame).
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;
+int communicators(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    auto it = g_comms.find(devices);
+    if (it == g_comms.end()) {
+        rccl_api &api = rccl();
+        if (!api.ok) return fail(RT_E_UNSUPPORTED, "rt_render_multi: RCCL is not available (%s)", api.why.c_str());
+        std::vector<ncclComm_t> comms(devices.size());
+        const ncclResult_t r = api.comm_init_all(comms.data(), (int)devices.size(), devices.data());
+        if (r != ncclSuccess) return fail(RT_E_DEVICE, "ncclCommInitAll over %zu devices: %s", devices.size(), api.error_string(r));
+        it = g_comms.emplace(devices, std::move(comms)).first;
+    }
+    out = it->second;
+    return RT_OK;
+}
+
+// what one GPU of a multi-GPU frame holds between the render and the reduction
+struct gpu_share {
+    int device = 0;
+    std::vector<uint32_t> scenes;   // indices into the caller's list, in its order
+    hipStream_t stream = nullptr;
+    void *accum = nullptr;
+    double kernel_ms = 0;
+    uint64_t rays = 0;
+    int rc = RT_OK;
+    std::string error;
+};
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_multi(rt_scene *const *scenes, uint32_t n_scenes, const rt_camera *camera, const rt_render_params *pr, void *accum_host,
+                    rt_stats *stats) {
+    if (!scenes || n_scenes == 0) return fail(RT_E_INVALID, "rt_render_multi: no scenes");
+    for (uint32_t g = 0; g < n_scenes; ++g)
+        if (int rc = check_render_args("rt_render_multi", scenes[g], camera, pr, accum_host)) return rc;
+    const size_t n_values = (size_t)pr->nx * pr->ny * 3;
+    const size_t bytes = n_values * (pr->accum_type == RT_ACCUM_F32 ? sizeof(float) : sizeof(double));
+    try {
+        // the GPUs of the list, in order of first appearance; scenes on the same GPU share its buffer
+        std::vector<gpu_share> gpus;
+        for (uint32_t g = 0; g < n_scenes; ++g) {
+            size_t k = 0;
+            while (k < gpus.size() && gpus[k].device != scenes[g]->device) ++k;
+            if (k == gpus.size()) { gpus.emplace_back(); gpus[k].device = scenes[g]->device; }
+            gpus[k].scenes.push_back(g);
+        }
+        // RTIOW_FORCE_RCCL=1 runs the reduction over a single GPU too (a one-rank communicator): the
+        // whole RCCL call sequence on a machine with one GPU
+        const bool collective = gpus.size() > 1 || getenv("RTIOW_FORCE_RCCL");
+        std::vector<ncclComm_t> comms;
+        if (collective) {
+            std::vector<int> devices;
+            for (const gpu_share &s : gpus) devices.push_back(s.device);
+            if (int rc = communicators(devices, comms)) return rc;
+        }
+        const uint32_t b = pr->sample_begin, spp = pr->sample_end - pr->sample_begin;
+        auto each_gpu = [&](auto work) {   // work(share, rank) on one host thread per GPU; false if any failed
+            std::vector<std::thread> threads;
+            try {
+                for (size_t k = 1; k < gpus.size(); ++k) threads.emplace_back([&, k] { work(gpus[k], (int)k); });
+            } catch (...) {   // no more threads to be had: the ones that started finish, then the call fails
+                for (std::thread &t : threads) t.join();
+                throw;
+            }
+            work(gpus[0], 0);
+            for (std::thread &t : threads) t.join();
+            for (const gpu_share &s : gpus)
+                if (s.rc != RT_OK) return false;
+            return true;
+        };
+        auto failed = [](gpu_share &s, int rc, const char *what, const char *detail) {
+            s.rc = rc;
+            s.error = std::string(what) + ": " + detail;
+        };
+        // every GPU renders its scenes' sample ranges into its own sums
+        bool ok = each_gpu([&](gpu_share &s, int) {
+            hipError_t e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMalloc(&s.accum, bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(s.accum, 0, bytes, s.stream);
+            if (e != hipSuccess) return failed(s, RT_E_DEVICE, "rt_render_multi: set-up", hipGetErrorString(e));
+            for (uint32_t g : s.scenes) {
+                rt_render_params p = *pr;
+                p.sample_begin = b + (uint32_t)((uint64_t)spp * g / n_scenes);
+                p.sample_end = b + (uint32_t)((uint64_t)spp * (g + 1) / n_scenes);
+                if (p.sample_end == p.sample_begin) continue;
+                rt_stats st;
+                if (int rc = rt_render(scenes[g], camera, &p, s.accum, s.stream, &st)) return failed(s, rc, "rt_render_multi", g_err);
+                s.kernel_ms += st.kernel_ms;
+                s.rays += st.rays;
+            }
+        });
+        // ... then the sums meet on the first GPU (only when every render went through: a rank that
+        // stayed away would leave the others waiting in the collective)
+        if (ok && collective)
+            ok = each_gpu([&](gpu_share &s, int rank) {
+                hipError_t e = hipSetDevice(s.device);
+                if (e != hipSuccess) return failed(s, RT_E_DEVICE, "rt_render_multi: hipSetDevice", hipGetErrorString(e));
+                const ncclResult_t r = rccl().reduce(s.accum, s.accum, n_values, pr->accum_type == RT_ACCUM_F32 ? ncclFloat : ncclDouble, ncclSum, 0,
+                                                     comms[(size_t)rank], s.stream);
+                if (r != ncclSuccess) return failed(s, RT_E_DEVICE, "ncclReduce", rccl().error_string(r));
+                e = hipStreamSynchronize(s.stream);
+                if (e != hipSuccess) return failed(s, RT_E_DEVICE, "rt_render_multi: reduction", hipGetErrorString(e));
+            });
+        if (ok) {
+            gpu_share &s = gpus[0];
+            hipError_t e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+            if (e == hipSuccess) e = hipMemcpy(accum_host, s.accum, bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { failed(s, RT_E_DEVICE, "rt_render_multi: copy to host", hipGetErrorString(e)); ok = false; }
+        }
+        int rc = RT_OK, where = 0;
+        std::string why;
+        for (gpu_share &s : gpus) {
+            (void)hipSetDevice(s.device);
+            if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+            if (s.accum) (void)hipFree(s.accum);
+            if (s.rc != RT_OK && rc == RT_OK) { rc = s.rc; why = s.error; where = s.device; }
+        }
+        if (rc != RT_OK) return fail(rc, "%s (device %d, %zu GPUs in the call)", why.c_str(), where, gpus.size());
+        if (stats) {
+            stats->paths = (uint64_t)pr->nx * pr->ny * spp;
+            stats->rays = 0;
+            stats->kernel_ms = 0;
+            for (const gpu_share &s : gpus) { stats->rays += s.rays; stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); }
+        }
+        return RT_OK;
+    } catch (const std::exception &e) {   // thread or memory exhaustion
+        return fail(RT_E_DEVICE, "rt_render_multi: %s", e.what());
+    }
 }
 
 int rt_resolve(int device, const float *accum_dev, size_t npix, uint32_t spp, uint8_t *rgb8_dev, void *stream) {

@@ -3,6 +3,7 @@
 // camera::get_ray, aabb::hit, one call at a time, each of which runs on the GPU.  The record
 // layouts are those of the golden vectors under tests/golden/ (raw little-endian doubles),
 // so tests/test_host_api_gpu.py can compare the output files with them directly.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -203,6 +204,20 @@ int main(int argc, char** argv) try {
         std::printf("build_world: %llu paths %llu rays\n", (unsigned long long)g.stats.paths, (unsigned long long)g.stats.rays);
         colour const c = g.pixel(20, 10);
         std::printf("pixel: %g %g %g\n", c.red(), c.green(), c.blue());
+        // render_options::devices: one GPU in the list is the single-GPU frame; the same GPU twice splits the
+        // samples between two uploads of the world, which render one after the other into that GPU's sums
+        opt.ns = 6;
+        int dev = 0;
+        frame const one = render(book, cam, opt);
+        opt.devices = {dev};
+        frame const listed = render(book, cam, opt);
+        opt.devices = {dev, dev};
+        frame const twice = render(book, cam, opt);
+        double worst = 0;
+        for (size_t i = 0; i < one.sums.size(); ++i) worst = std::fmax(worst, std::fabs((double)twice.sums[i] - (double)one.sums[i]));
+        std::printf("devices: one listed %s, split in two: %llu rays of %llu, largest difference of the sums %.3g\n",
+                    listed.sums == one.sums && listed.stats.rays == one.stats.rays ? "equal" : "DIFFERENT",
+                    (unsigned long long)twice.stats.rays, (unsigned long long)one.stats.rays, worst);
         return 0;
     }
     std::fprintf(stderr, "usage: host_api_check hit|scatter|camera|texture|aabb|errors ...\n");

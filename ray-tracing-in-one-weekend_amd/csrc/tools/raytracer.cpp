@@ -1,5 +1,5 @@
 // raytracer.cpp -- the frame driver: builds a world with the scene API, renders it on
-// one MI355X and writes the image as the reference's main() does (main.cpp:107-151):
+// one MI355X (or, with --devices, on several: the samples are split between them) and writes the image as the reference's main() does (main.cpp:107-151):
 // "Render duration" on stderr, P3 text on stdout.  The reference fixes scene, size and
 // sample count at compile time (main.cpp:108,113); here they are flags whose defaults
 // are those constants.  --camera takes the view the reference hard-codes at main.cpp:114-120
@@ -13,6 +13,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <vector>
 
 #include "recipe.hpp"
 #include "rtiow.hpp"
@@ -22,7 +23,7 @@ using namespace rtiow;
 static int usage() {
     std::fprintf(stderr,
                  "usage: raytracer [--scene two_perlin|book1|book2|stress|FILE.recipe] [--nx N] [--ny N] [--ns N]\n"
-                 "                 [--seed S] [--scene-seed S] [--spheres N] [--device D] [--aperture A] [--focus F]\n"
+                 "                 [--seed S] [--scene-seed S] [--spheres N] [--device D | --devices D0,D1,...] [--aperture A] [--focus F]\n"
                  "                 [--camera FX,FY,FZ,AX,AY,AZ,VFOV] [--out FILE] [--format p3|p6|png] [--binary]\n"
                  "  without --format the suffix of FILE decides (.png: png, else p3); --binary is --format p6\n");
     return 2;
@@ -50,6 +51,14 @@ int main(int argc, char** argv) {
         else if (a == "--scene-seed") scene_seed = (uint32_t)std::strtoul(need("--scene-seed"), nullptr, 10);
         else if (a == "--spheres") spheres = std::atoi(need("--spheres"));
         else if (a == "--device") opt.device = std::atoi(need("--device"));
+        else if (a == "--devices") {
+            for (char const* p = need("--devices"); *p;) {
+                char* end = nullptr;
+                opt.devices.push_back((int)std::strtol(p, &end, 10));
+                if (end == p) return usage();
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "--aperture") aperture = std::atof(need("--aperture"));
         else if (a == "--out") out_path = need("--out");
         else if (a == "--binary") format = "p6";
@@ -73,9 +82,12 @@ int main(int argc, char** argv) {
         std::unique_ptr<object const> world = rc.instantiate(mt);
         // the camera of main.cpp:114-120
         camera const cam{mt, vec3{view[0], view[1], view[2]}, vec3{view[3], view[4], view[5]}, vec3{0, 1, 0}, view[6], double(opt.nx) / double(opt.ny), aperture, focus, 0, 1};
-        device_scene const dev(*world, opt.device);
+        std::unique_ptr<device_scene> dev;
+        std::vector<std::unique_ptr<device_scene>> devs;
+        if (opt.devices.empty()) dev = std::make_unique<device_scene>(*world, opt.device);
+        else devs = upload(*world, opt.devices);
         auto const start = std::chrono::steady_clock::now();
-        frame const f = render(dev, cam, opt);
+        frame const f = dev ? render(*dev, cam, opt) : render(devs, cam, opt);
         auto const end = std::chrono::steady_clock::now();
         double const secs = std::chrono::duration<double>(end - start).count();
         std::fprintf(stderr, "Render duration: %gs\n", secs);

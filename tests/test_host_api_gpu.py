@@ -105,6 +105,11 @@ def test_errors_and_builders():
     assert "empty: 0" in out
     assert "mean gamma: 0.70710678118654757 0.70710678118654757 0.70710678118654757" in out
     assert "two_perlin: 3200 paths" in out and "build_world: 3200 paths" in out
+    # render_options::devices = {0} is the single-GPU frame; {0, 0} splits the samples and traces the same rays
+    line = [l for l in out.splitlines() if l.startswith("devices:")][0]
+    assert "one listed equal" in line
+    rays = [int(x) for x in line.replace(",", " ").split() if x.isdigit()]
+    assert rays[0] == rays[1] and float(line.split()[-1]) < 1e-5
 
 
 def test_frame_driver_writes_the_reference_ppm_and_its_binary_twin(tmp_path, rt):
@@ -126,6 +131,9 @@ def test_frame_driver_writes_the_reference_ppm_and_its_binary_twin(tmp_path, rt)
     # .png: the same bytes again, in a container any viewer opens
     subprocess.run(common + ["--out", str(tmp_path / "c.png")], check=True, capture_output=True, timeout=300)
     assert np.array_equal(decode_png((tmp_path / "c.png").read_bytes()), p6)
+    # --devices 0: the list of GPUs with one entry writes the same file
+    subprocess.run(common + ["--out", str(tmp_path / "d.ppm"), "--devices", "0"], check=True, capture_output=True, timeout=300)
+    assert (tmp_path / "d.ppm").read_text() == (tmp_path / "a.ppm").read_text()
     # and they are the resolve of the library's own sums for the same seed
     cam15 = np.array(golden("frames")["camera"])
     cam15[10] = 50 / 26

@@ -130,3 +130,62 @@ def test_4k_frame_properties(rt):
     assert abs(small.mean() - half.mean() / 16) < 2e-4
     coarse = lambda x: x.reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
     assert np.sqrt(np.mean((coarse(small) - coarse(half / 16)) ** 2)) < 0.01
+
+
+def test_render_multi_on_the_gpus_at_hand(rt):
+    # rt_render_multi, the C entry point behind render_options::devices: one scene is rt_render's frame to
+    # the bit; two uploads of the world on the same GPU split the samples [g S / 2, (g + 1) S / 2) and add
+    # their float sums in that GPU's buffer -- the sum of the two ranges rendered alone, to the bit, and the
+    # whole range up to float rounding; ray counts add up.
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = 96 / 54
+    cam = rt.camera(cam15)
+    w, w2 = rt.World(recipe("book2"), device=0), rt.World(recipe("book2"), device=0)
+    try:
+        whole, st = w.render(cam, 96, 54, 3, 12, 9, rt.RT_ACCUM_F32)
+        one, st1 = rt.render_multi([w], cam, 96, 54, 3, 12, 9)
+        a, sa = w.render(cam, 96, 54, 3, 7, 9, rt.RT_ACCUM_F32)
+        b, sb = w.render(cam, 96, 54, 7, 12, 9, rt.RT_ACCUM_F32)
+        two, st2 = rt.render_multi([w, w2], cam, 96, 54, 3, 12, 9)
+        three, st3 = rt.render_multi([w, w2, w], cam, 96, 54, 0, 2, 9)          # fewer samples than scenes: one share is empty
+        d64, _ = rt.render_multi([w, w2], cam, 96, 54, 3, 12, 9, accum=rt.RT_ACCUM_F64)
+        whole64, _ = w.render(cam, 96, 54, 3, 12, 9, rt.RT_ACCUM_F64)
+        few, _ = w.render(cam, 96, 54, 0, 2, 9, rt.RT_ACCUM_F32)
+    finally:
+        w.close()
+        w2.close()
+    assert np.array_equal(one, whole) and st1.rays == st.rays and st1.paths == st.paths
+    assert np.array_equal(two, a + b) and st2.rays == sa.rays + sb.rays == st.rays
+    np.testing.assert_allclose(two, whole, rtol=3e-7, atol=1e-6)
+    np.testing.assert_allclose(three, few, rtol=3e-7, atol=1e-6)
+    assert st3.paths == 96 * 54 * 2
+    np.testing.assert_allclose(d64, whole64, rtol=1e-13, atol=1e-13)
+
+
+RCCL_IN_THE_LIBRARY = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rt = importlib.import_module("ray-tracing-in-one-weekend_amd")
+cam15 = [13.0, 2.0, 3.0, 0, 0, 0, 0, 1.0, 0, 20.0, 2.0, 0.0, 10.0, 0.0, 1.0]
+cam = rt.camera(cam15)
+w = rt.World(os.path.join(sys.argv[1], "tests", "golden", "scenes", "book2.recipe"), device=0)
+plain, st = rt.render_multi([w], cam, 64, 32, 0, 8, 5)
+assert "librccl" not in open("/proc/self/maps").read(), "one GPU, no collective: RCCL must not have been loaded"
+os.environ["RTIOW_FORCE_RCCL"] = "1"
+forced, st2 = rt.render_multi([w], cam, 64, 32, 0, 8, 5)
+again, st3 = rt.render_multi([w], cam, 64, 32, 0, 8, 5)          # the communicator is kept between calls
+assert "librccl" in open("/proc/self/maps").read()
+assert np.array_equal(plain, forced) and np.array_equal(plain, again) and st.rays == st2.rays == st3.rays
+w.close()
+print("ok", float(plain.mean()))
+'''
+
+
+def test_the_librarys_own_rccl_reduction_over_one_rank():
+    # rt_render_multi opens librccl.so.1 itself, makes its communicators with ncclCommInitAll and merges the
+    # GPUs' sums with ncclReduce.  One GPU needs none of it (and loads none of it); RTIOW_FORCE_RCCL=1 runs
+    # the same calls over the one-rank communicator: the frame comes back unchanged.
+    r = subprocess.run([sys.executable, "-c", RCCL_IN_THE_LIBRARY, ROOT], env=ENV, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("ok")
