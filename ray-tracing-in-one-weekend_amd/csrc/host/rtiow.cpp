@@ -15,6 +15,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <exception>
 
@@ -91,6 +92,25 @@ bool aabb::hit(ray const& r, double tmin, double tmax) const {
 }
 
 // ------------------------------------------------------------------ flattening ----
+// Appends another flattener's tables (a subtree flattened on its own); `ref` is a reference into them --
+// a node index, or ~(primitive index) -- and comes back as the reference into this one.
+int32_t scene_flattener::append(scene_flattener const& o, int32_t ref) {
+    int32_t const node_base = (int32_t)nodes.size(), prim_base = (int32_t)prims.size();
+    uint32_t const mat_base = (uint32_t)materials.size(), tex_base = (uint32_t)textures.size();
+    auto moved = [&](int32_t x) { return x >= 0 ? x + node_base : x - prim_base; };
+    nodes.reserve(nodes.size() + o.nodes.size());
+    for (rt_node_desc n : o.nodes) { n.left = moved(n.left); n.right = moved(n.right); nodes.push_back(n); }
+    prims.reserve(prims.size() + o.prims.size());
+    for (rt_prim_desc q : o.prims) { q.material += mat_base; prims.push_back(q); }
+    materials.reserve(materials.size() + o.materials.size());
+    for (rt_material_desc m : o.materials) { if (m.kind == RT_MAT_LAMBERTIAN) m.texture += tex_base; materials.push_back(m); }
+    textures.reserve(textures.size() + o.textures.size());
+    for (rt_texture_desc t : o.textures) { if (t.kind == RT_TEX_CHEQUER) { t.even += tex_base; t.odd += tex_base; } textures.push_back(t); }
+    material_of_prim.insert(material_of_prim.end(), o.material_of_prim.begin(), o.material_of_prim.end());
+    for (rt_item_desc it : o.items) { it.index = it.is_bvh ? it.index + node_base : it.index + prim_base; items.push_back(it); }
+    return moved(ref);
+}
+
 rt_scene_desc scene_flattener::desc() const {
     rt_scene_desc d{};
     d.textures = textures.data(); d.n_textures = (uint32_t)textures.size();
@@ -465,7 +485,53 @@ struct bvh_node::build_plan {
     std::map<size_t, size_t> node_count;  // nodes_over, for the sizes that occur
     double t0, t1;
     int parallel_depth;                   // halves of large nodes are built by threads of their own above this depth
+    bool arranged = false;                // the objects already stand in the tree's left-to-right order (see arrange)
 };
+
+// A large tree without the sorts.  What a node's sort decides is which objects go left: the n / 2 with the
+// smallest keys.  When the largest key of that half is smaller than the smallest of the other, the two sets
+// are the same whatever the order the objects arrived in and whatever the algorithm -- a selection
+// (std::nth_element, linear) finds them as well as the reference's sort, and the order inside a half is the
+// business of the half's own node, by its own axis.  arrange() permutes the objects' keys that way, node by
+// node, into the left-to-right order of the tree's leaves, and reports failure the moment a node's split is
+// NOT decided by the keys alone (equal keys across the cut, or in a node of two): the build then takes the
+// reference's road from the start, sorts and all, since the outcome of an unstable sort over equal keys
+// depends on the order of its input, all the way up.  O(n log n) instead of O(n log^2 n) comparisons, one
+// bounding_box call per object instead of one per object and level.
+namespace {
+struct keyed3 { double lo[3]; object const* ptr; };
+constexpr size_t kArrangeMin = size_t(1) << 16;   // groups at least this large are arranged (smaller ones: the sorts are cheap)
+}  // namespace
+
+bool bvh_node::arrange(build_plan const& plan, void* keys, size_t const n, size_t const index, int const depth) {
+    keyed3* const a = static_cast<keyed3*>(keys);
+    int const axis = plan.axis[index];
+    if (n <= 1) return true;
+    if (n == 2) {
+        if (a[0].lo[axis] == a[1].lo[axis]) return false;
+        if (a[1].lo[axis] < a[0].lo[axis]) std::swap(a[0], a[1]);
+        return true;
+    }
+    size_t const half = n / 2;
+    std::nth_element(a, a + half, a + n, [axis](keyed3 const& l, keyed3 const& r) { return l.lo[axis] < r.lo[axis]; });
+    double const pivot = a[half].lo[axis];
+    for (size_t i = 0; i < half; ++i)
+        if (!(a[i].lo[axis] < pivot)) return false;
+    size_t const left_index = index + 1, right_index = left_index + (half <= 2 ? 1 : plan.node_count.at(half));
+    if (n >= kParallelBuildMin && depth < plan.parallel_depth) {
+        bool ok_left = false;
+        bool started = false;
+        std::thread other;
+        try {
+            other = std::thread([&] { ok_left = arrange(plan, a, half, left_index, depth + 1); });
+            started = true;
+        } catch (std::system_error const&) {}
+        bool const ok_right = arrange(plan, a + half, n - half, right_index, depth + 1);
+        if (started) other.join(); else ok_left = arrange(plan, a, half, left_index, depth + 1);
+        return ok_left && ok_right;
+    }
+    return arrange(plan, a, half, left_index, depth + 1) && arrange(plan, a + half, n - half, right_index, depth + 1);
+}
 
 bvh_node::build_plan bvh_node::draw_axes(std::mt19937& mt, size_t n, double t0, double t1) {
     build_plan plan;
@@ -478,9 +544,45 @@ bvh_node::build_plan bvh_node::draw_axes(std::mt19937& mt, size_t n, double t0, 
     return plan;
 }
 
+// the plan for `objects`, which are put into the tree's leaf order here when the keys decide every split
+bvh_node::build_plan bvh_node::prepare(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double const t0, double const t1) {
+    build_plan plan = draw_axes(mt, objects.size(), t0, t1);
+    char const* const off = std::getenv("RTIOW_BUILD_ARRANGE");     // "0": always the reference's sorts (tests)
+    if (objects.size() < kArrangeMin || (off && std::atoi(off) == 0)) return plan;
+    std::vector<keyed3> keys(objects.size());
+    {   // one bounding_box call per object, shared out over the cores
+        int const slices = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<char> unusable((size_t)slices, 0);
+        auto slice = [&](int t) {
+            for (size_t i = objects.size() * (size_t)t / (size_t)slices; i < objects.size() * (size_t)(t + 1) / (size_t)slices; ++i) {
+                object const* const o = objects[i].get();
+                std::optional<aabb> const b = o != nullptr ? o->bounding_box(t0, t1) : std::nullopt;
+                if (!b) { unusable[(size_t)t] = 1; return; }             // (the reference's road throws the reference's literal)
+                vec3 const lo = b->min();
+                keys[i] = keyed3{{lo.x(), lo.y(), lo.z()}, o};
+                if (std::isnan(lo.x()) || std::isnan(lo.y()) || std::isnan(lo.z())) { unusable[(size_t)t] = 1; return; }
+            }
+        };
+        std::vector<std::thread> threads;
+        try {
+            for (int t = 1; t < slices; ++t) threads.emplace_back(slice, t);
+        } catch (std::system_error const&) {}
+        int const started = (int)threads.size() + 1;
+        slice(0);
+        for (int t = started; t < slices; ++t) slice(t);
+        for (std::thread& t : threads) t.join();
+        for (char u : unusable) if (u) return plan;
+    }
+    if (!arrange(plan, keys.data(), keys.size(), 0, 0)) return plan;
+    for (auto& o : objects) (void)o.release();   // every pointer is in `keys` now
+    for (size_t i = 0; i < keys.size(); ++i) objects[i].reset(keys[i].ptr);
+    plan.arranged = true;
+    return plan;
+}
+
 // bvh_node.cpp:8-50
 bvh_node::bvh_node(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double const t0, double const t1)
-    : bvh_node(draw_axes(mt, objects.size(), t0, t1), objects, 0, 0) {}
+    : bvh_node(prepare(mt, objects, t0, t1), objects, 0, 0) {}
 
 bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object const>> objects, size_t const index, int const depth)
     : n_objects(objects.size()) {
@@ -491,7 +593,7 @@ bvh_node::bvh_node(build_plan const& plan, std::span<std::unique_ptr<object cons
     // only on the two objects' box minima along the axis, and the permutation a sort produces
     // depends only on the outcomes, so sorting (key, pointer) pairs with the same algorithm
     // gives the same order -- ties and all -- at a fraction of the cost for large scenes.
-    if (objects.size() > 1) {
+    if (objects.size() > 1 && !plan.arranged) {
         struct keyed { double key; object const* ptr; };
         constexpr size_t kSmall = 16;
         keyed small[kSmall];
@@ -595,8 +697,34 @@ int32_t bvh_node::flatten_child(scene_flattener& out, aabb const&) const {
     }
     int32_t const me = (int32_t)out.nodes.size();
     out.nodes.emplace_back();
-    int32_t const l = left->flatten_child(out, *box);
-    int32_t const r = (right == left) ? l : right->flatten_child(out, *box);
+    int32_t l, r;
+    // The two halves of a large node flatten side by side: the right one into tables of its own, which are
+    // then appended with their references moved along.  Entry for entry what one thread writes (the tables
+    // list a subtree's entries in the order of a left-to-right walk either way).
+    bool split = false;
+    if (n_objects >= kParallelFlatten && right != left) {
+        scene_flattener local;
+        int32_t r_local = 0;
+        std::exception_ptr failed;
+        try {
+            std::thread other([&] {
+                try { r_local = right->flatten_child(local, *box); } catch (...) { failed = std::current_exception(); }
+            });
+            split = true;
+            try { l = left->flatten_child(out, *box); } catch (...) { other.join(); throw; }
+            other.join();
+        } catch (std::system_error const&) {
+            if (split) throw;     // (it came out of a subtree, not out of starting the thread)
+        }
+        if (split) {
+            if (failed) std::rethrow_exception(failed);
+            r = out.append(local, r_local);
+        }
+    }
+    if (!split) {
+        l = left->flatten_child(out, *box);
+        r = (right == left) ? l : right->flatten_child(out, *box);
+    }
     rt_node_desc n{};
     n.box_min[0] = box->min().x(); n.box_min[1] = box->min().y(); n.box_min[2] = box->min().z();
     n.box_max[0] = box->max().x(); n.box_max[1] = box->max().y(); n.box_max[2] = box->max().z();

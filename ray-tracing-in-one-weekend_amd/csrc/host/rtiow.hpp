@@ -98,6 +98,7 @@ public:
     std::vector<material const*> material_of_prim;  // hit_record.material for each primitive
 
     rt_scene_desc desc() const;
+    int32_t append(scene_flattener const& other, int32_t ref);
 };
 
 // The GPU used by the per-ray calls that bring no scene of their own -- aabb::hit,
@@ -274,9 +275,12 @@ class bvh_node final : public object {
     object const* right = nullptr;
     std::optional<aabb> box;
     size_t n_objects = 0;   // objects under this node
+    static constexpr size_t kParallelFlatten = size_t(1) << 16;   // a node over this many objects flattens its halves on two threads
     // the axis of every node, drawn before the build (see rtiow.cpp)
     struct build_plan;
     static build_plan draw_axes(std::mt19937& mt, size_t n, double t0, double t1);
+    static build_plan prepare(std::mt19937& mt, std::span<std::unique_ptr<object const>> objects, double t0, double t1);
+    static bool arrange(build_plan const& plan, void* keys, size_t n, size_t index, int depth);
     bvh_node(build_plan const& plan, std::span<std::unique_ptr<object const>> objects, size_t index, int depth);
 public:
     // Same build as the reference (bvh_node.cpp:8-50): random axis, std::ranges::sort on

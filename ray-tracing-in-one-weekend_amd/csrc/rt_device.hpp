@@ -70,6 +70,24 @@ __host__ __device__ inline float plane_up(double v) {
     return f;
 }
 
+// The box a single static sphere gets in trees that go down to single spheres (scenes without moving
+// spheres): the radius, 2^-20 of it, and 2^-30 of the largest coordinate (a radius of zero, or one far below
+// the centre's magnitude, still gets a box wider than the sphere test's rounding), and, when the scene allows
+// it (far_allowance > 0), what the rounding of the reference's discriminant can add for a ray that starts
+// up to far_allowance from the centre (see FarSlack).  b = min x, max x, min y, ...
+__host__ __device__ inline double far_slack_pad(double radius, double far_allowance) {
+    if (!(far_allowance > 0)) return 0;
+    const double a = 0x1p-49 * far_allowance * far_allowance / radius, b = 0x1p-23 * far_allowance;
+    return (a < b ? a : b) * (1 + 0x1p-10);   // (a NaN -- a zero radius -- takes b)
+}
+__host__ __device__ inline void sphere_pad_box(const double *c0, double radius, double far_allowance, double *b) {
+    const double ax = c0[0] < 0 ? -c0[0] : c0[0], ay = c0[1] < 0 ? -c0[1] : c0[1], az = c0[2] < 0 ? -c0[2] : c0[2];
+    const double far = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+    const double ar = radius < 0 ? -radius : radius;
+    const double r = ar * (1.0 + 0x1p-20) + 0x1p-30 * (far + ar) + far_slack_pad(ar, far_allowance);
+    for (int a = 0; a < 3; ++a) { b[2 * a] = c0[a] - r; b[2 * a + 1] = c0[a] + r; }
+}
+
 // Every primitive under a SAFE child stays inside the child's box (static spheres), so
 // the descent may be skipped once the box starts beyond the best hit.  A moving sphere
 // leaves the box the reference gives it (moving_sphere.cpp:58), but not by more than the scene's

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "rt_device.hpp"
+#include "bvh_device.hpp"
 #include "rtiow_hip.h"
 
 using namespace rtd;
@@ -637,9 +638,8 @@ struct flattener {
     const char *error = nullptr;
 
     // fills a primitive entry; returns its leaf-reference bits for slot `second`
-    int32_t emit_prim(int32_t id, bool second, bool &safe) {
+    int32_t fill_prim(DPrim &d, int32_t id, bool second, bool &safe) const {
         const rt_prim_desc &p = desc->prims[id];
-        DPrim d;
         memset(&d, 0, sizeof d);
         for (int k = 0; k < 3; ++k) { d.c0[k] = p.centre0[k]; d.dc[k] = p.centre1[k] - p.centre0[k]; }
         d.r = p.radius; d.t0 = p.time0; d.t1 = p.time1;
@@ -654,25 +654,33 @@ struct flattener {
         }
         // a sphere that never moves stays inside the box the reference gives it
         safe = !moving;
-        prims.push_back(d);
         return moving ? (second ? LEAF_MOVING1 : LEAF_MOVING0) : 0;
     }
 
-    // appends a leaf of one sphere (prim_b == prim_a) or two; `box` is the box the reference tests
-    // before it tries them (min x, max x, min y, ...; unbounded when it tries them unconditionally)
-    int32_t leaf_of(int32_t prim_a, int32_t prim_b, const double *box, bool &safe) {
+    // Fills leaf number `leaf` -- its box and entries 2 leaf, 2 leaf + 1 of the primitive table, which exist
+    // already -- with one sphere (prim_b == prim_a) or two; `box` is the box the reference tests before it
+    // tries them (min x, max x, min y, ...; unbounded when it tries them unconditionally).  Returns the
+    // leaf's reference.
+    int32_t fill_leaf(size_t leaf, int32_t prim_a, int32_t prim_b, const double *box, bool &safe) {
         bool sa = true, sb = true;
-        if (leaf_boxes.size() >= (size_t)LEAF_INDEX_MASK) { error = "more than 2^26 leaves"; return REF_NONE; }
-        int32_t ref = LEAF_BIT | (int32_t)leaf_boxes.size();
-        DLeaf lf;
-        memcpy(lf.box, box, sizeof lf.box);
-        leaf_boxes.push_back(lf);
-        ref |= emit_prim(prim_a, false, sa);
-        if (prim_b != prim_a) ref |= LEAF_TWO | emit_prim(prim_b, true, sb);
-        else { DPrim unused; memset(&unused, 0, sizeof unused); unused.orig = -1; prims.push_back(unused); }
+        int32_t ref = LEAF_BIT | (int32_t)leaf;
+        memcpy(leaf_boxes[leaf].box, box, sizeof leaf_boxes[leaf].box);
+        ref |= fill_prim(prims[2 * leaf], prim_a, false, sa);
+        if (prim_b != prim_a) ref |= LEAF_TWO | fill_prim(prims[2 * leaf + 1], prim_b, true, sb);
+        else { DPrim &unused = prims[2 * leaf + 1]; memset(&unused, 0, sizeof unused); unused.orig = -1; }
         safe = sa && sb;
         if (safe) ref |= LEAF_SAFE;
-        else ++n_moving_leaves;
+        return ref;
+    }
+
+    // appends a leaf (see fill_leaf)
+    int32_t leaf_of(int32_t prim_a, int32_t prim_b, const double *box, bool &safe) {
+        if (leaf_boxes.size() >= (size_t)LEAF_INDEX_MASK) { error = "more than 2^26 leaves"; return REF_NONE; }
+        const size_t leaf = leaf_boxes.size();
+        leaf_boxes.emplace_back();
+        prims.resize(prims.size() + 2);
+        const int32_t ref = fill_leaf(leaf, prim_a, prim_b, box, safe);
+        if (!safe) ++n_moving_leaves;
         return ref;
     }
 
@@ -744,29 +752,84 @@ struct flattener {
     struct leaf_rec { int32_t ref; double box[6]; bool safe; };
     std::vector<leaf_rec> leaves;
 
-    void collect(int32_t id, uint32_t depth) {
-        if (error) return;
-        if (depth > 64) { error = "bvh deeper than 64 levels (or cyclic)"; return; }
+    // The leaves under description node `id`, left to right, appended to `leaves` (and to the leaf and
+    // primitive tables).  Two walks, so that large subtrees can be shared out between threads: the first
+    // counts the leaves under every node, the second fills them in at the places the counts assign.
+    static constexpr uint32_t kParallelLeaves = 1u << 15;   // a subtree with this many leaves is worth a thread
+    static constexpr uint32_t kParallelCollectDepth = 5;
+    std::vector<uint32_t> leaves_under;   // by description node (filled by count_leaves)
+
+    uint32_t count_leaves(int32_t id, uint32_t depth, const char *&problem) {
+        if (depth > 64) { problem = "bvh deeper than 64 levels (or cyclic)"; return 0; }
         const rt_node_desc nd = desc->nodes[id];
         const int32_t ref[2] = {nd.left, nd.right};
         for (int c = 0; c < 2; ++c)
-            if (ref[c] >= 0 ? (uint32_t)ref[c] >= desc->n_nodes : (uint32_t)~ref[c] >= desc->n_prims) { error = "node child out of range"; return; }
+            if (ref[c] >= 0 ? (uint32_t)ref[c] >= desc->n_nodes : (uint32_t)~ref[c] >= desc->n_prims) { problem = "node child out of range"; return 0; }
+        uint64_t n = 0;
+        if (ref[0] < 0 && ref[1] < 0) n = 1;
+        else if (ref[0] >= 0 && ref[1] == ref[0]) n = count_leaves(ref[0], depth + 1, problem);   // one object as both children (bvh_node.cpp:31-34): its leaves once
+        else if (ref[0] >= 0 && ref[1] >= 0 && depth < kParallelCollectDepth && desc->n_nodes >= 2 * kParallelLeaves) {
+            uint32_t left = 0;
+            const char *left_problem = nullptr;
+            bool started = false;
+            std::thread other;
+            try { other = std::thread([&] { left = count_leaves(ref[0], depth + 1, left_problem); }); started = true; } catch (const std::system_error &) {}
+            const uint32_t right = count_leaves(ref[1], depth + 1, problem);
+            if (started) other.join(); else left = count_leaves(ref[0], depth + 1, left_problem);
+            if (left_problem) problem = left_problem;
+            n = (uint64_t)left + right;
+        } else {
+            for (int c = 0; c < 2; ++c) n += ref[c] >= 0 ? count_leaves(ref[c], depth + 1, problem) : 1u;
+        }
+        if (n >= (uint64_t)LEAF_INDEX_MASK) { problem = "more than 2^26 leaves"; n = 0; }
+        leaves_under[(size_t)id] = (uint32_t)n;
+        return (uint32_t)n;
+    }
+
+    // fills leaves[at, at + leaves_under[id]) and the tables' entries from first_leaf + at on; returns how many held a moving sphere
+    size_t fill_leaves(int32_t id, size_t at, size_t first_leaf) {
+        const rt_node_desc nd = desc->nodes[id];
+        const int32_t ref[2] = {nd.left, nd.right};
         leaf_rec lr;
         for (int a = 0; a < 3; ++a) { lr.box[2 * a] = nd.box_min[a]; lr.box[2 * a + 1] = nd.box_max[a]; }
         if (ref[0] < 0 && ref[1] < 0) {
-            lr.ref = leaf_of(~ref[0], ~ref[1], lr.box, lr.safe);
-            leaves.push_back(lr);
-            return;
+            lr.ref = fill_leaf(first_leaf + at, ~ref[0], ~ref[1], lr.box, lr.safe);
+            leaves[at] = lr;
+            return lr.safe ? 0 : 1;
         }
-        for (int c = 0; c < 2; ++c) {
-            if (c == 1 && ref[1] >= 0 && ref[1] == ref[0]) break;   // one object as both children (bvh_node.cpp:31-34): its leaves once
-            if (ref[c] >= 0) collect(ref[c], depth + 1);
-            else {   // a primitive beside a subtree is tested whenever this node's box is hit
-                lr.ref = leaf_of(~ref[c], ~ref[c], lr.box, lr.safe);
-                leaves.push_back(lr);
-            }
-            if (error) return;
+        if (ref[0] >= 0 && ref[1] == ref[0]) return fill_leaves(ref[0], at, first_leaf);
+        const size_t n_left = ref[0] >= 0 ? leaves_under[(size_t)ref[0]] : 1;
+        auto child = [&](int c, size_t where) -> size_t {
+            if (ref[c] >= 0) return fill_leaves(ref[c], where, first_leaf);
+            leaf_rec one = lr;   // a primitive beside a subtree is tested whenever this node's box is hit
+            one.ref = fill_leaf(first_leaf + where, ~ref[c], ~ref[c], one.box, one.safe);
+            leaves[where] = one;
+            return one.safe ? 0 : 1;
+        };
+        if (ref[0] >= 0 && ref[1] >= 0 && n_left >= kParallelLeaves && leaves_under[(size_t)ref[1]] >= kParallelLeaves) {
+            size_t moving_left = 0;
+            bool started = false;
+            std::thread other;
+            try { other = std::thread([&] { moving_left = child(0, at); }); started = true; } catch (const std::system_error &) {}
+            const size_t moving_right = child(1, at + n_left);
+            if (started) other.join(); else moving_left = child(0, at);
+            return moving_left + moving_right;
         }
+        return child(0, at) + child(1, at + n_left);
+    }
+
+    void collect(int32_t id) {
+        if (error) return;
+        leaves_under.assign(desc->n_nodes, 0);
+        const char *problem = nullptr;
+        const uint32_t n = count_leaves(id, 0, problem);
+        if (problem) { error = problem; return; }
+        const size_t first_leaf = leaf_boxes.size();
+        if (first_leaf + n >= (size_t)LEAF_INDEX_MASK) { error = "more than 2^26 leaves"; return; }
+        leaves.assign(n, leaf_rec{});
+        leaf_boxes.resize(first_leaf + n);
+        prims.resize(2 * (first_leaf + n));
+        n_moving_leaves += fill_leaves(id, 0, first_leaf);
     }
 
     static double half_area(const double *b) {
@@ -1039,16 +1102,10 @@ struct flattener {
             if (it.ref >= 0) it.ref = renum[it.ref];
     }
 
-    // the box a one-sphere reference gets in a scene of static spheres (see split_pairs)
+    // the box a one-sphere reference gets in a scene of static spheres (see split_pairs, sphere_pad_box)
     void sphere_box(int32_t prim, double *b) const {
         const DPrim &p = prims[(size_t)prim];
-        // the radius, 2^-20 of it, and 2^-30 of the largest coordinate (a radius of zero, or one far
-        // below the centre's magnitude, still gets a box wider than the test's rounding)
-        const double far = std::fmax(std::fmax(std::fabs(p.c0[0]), std::fabs(p.c0[1])), std::fabs(p.c0[2]));
-        // ... and, when the scene allows it (far_allowance > 0), what the rounding of the reference's
-        // discriminant can add for a ray that starts up to far_allowance from the centre (see FarSlack)
-        const double r = std::fabs(p.r) * (1.0 + 0x1p-20) + 0x1p-30 * (far + std::fabs(p.r)) + far_pad(std::fabs(p.r));
-        for (int a = 0; a < 3; ++a) { b[2 * a] = p.c0[a] - r; b[2 * a + 1] = p.c0[a] + r; }
+        sphere_pad_box(p.c0, p.r, far_allowance, b);
     }
 
     bool static_scene = false;   // no moving sphere: the tree is built over single spheres
@@ -1056,10 +1113,14 @@ struct flattener {
     // Static scenes: the largest distance between a ray's origin and a sphere's centre that the
     // padding of the spheres' own boxes covers (0: none is built in, every segment computes its slack).
     double far_allowance = 0;
-    double far_pad(double radius) const {
-        if (!(far_allowance > 0)) return 0;
-        return std::fmin(0x1p-49 * far_allowance * far_allowance / radius, 0x1p-23 * far_allowance) * (1 + 0x1p-10);
-    }
+    double far_pad(double radius) const { return far_slack_pad(radius, far_allowance); }
+
+    // Large scenes of static spheres: the tree over the single spheres is built on the GPU (bvh_device.hpp).
+    // The host then only lists the spheres (device_refs: one-sphere leaf references) and the box around
+    // their centres; the nodes are numbered from 0 on the device and never exist on the host.
+    bool device_build = false;
+    std::vector<int32_t> device_refs;
+    double device_lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, device_hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
 
     // the whole bvh item rooted at description node `id`, re-clustered
     int32_t build_clustered(int32_t id, bool &safe) {
@@ -1071,9 +1132,25 @@ struct flattener {
             t0 = t1;
         };
         leaves.clear();
-        collect(id, 0);
+        collect(id);
         lap("reference leaves collected");
         if (error) return REF_NONE;
+        if (static_scene && device_build && leaves.size() >= 2 && nodes.empty()) {
+            device_refs.reserve(2 * leaves.size());
+            for (const leaf_rec &lr : leaves) {
+                const int32_t leaf = lr.ref & LEAF_INDEX_MASK;
+                for (int k = 0; k < ((lr.ref & LEAF_TWO) ? 2 : 1); ++k) {
+                    device_refs.push_back(LEAF_BIT | LEAF_SAFE | leaf | (k ? LEAF_SECOND : 0));
+                    const double *c = prims[2 * (size_t)leaf + (size_t)k].c0;
+                    for (int a = 0; a < 3; ++a) { device_lo[a] = std::fmin(device_lo[a], c[a]); device_hi[a] = std::fmax(device_hi[a], c[a]); }
+                }
+            }
+            leaves.clear();
+            lap("spheres listed for the device build");
+            safe = true;
+            return 0;   // the device numbers its root 0
+        }
+        device_build = false;   // (not this item: the host clusters it)
         if (static_scene) {
             // cluster the spheres themselves rather than the reference's pairs of them: the pairs are
             // neighbours along a random axis, and a tree over their mostly empty boxes stays loose
@@ -1210,6 +1287,18 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         }
         if (!small) fl.far_allowance = 0;
     }
+    // Where the tree over the spheres of a static scene is built: on the GPU for large scenes with a single
+    // bvh (a linear BVH in milliseconds: set-up is most of such a scene's first frame), on the host otherwise
+    // (the surface-area clustering: the tighter tree).  RTIOW_BUILD=device|host decides for any size.
+    {
+        const char *build_env = getenv("RTIOW_BUILD");
+        const char *wide_switch = getenv("RTIOW_WIDE");
+        uint32_t n_bvh = 0;
+        for (uint32_t i = 0; i < desc->n_items; ++i) n_bvh += desc->items[i].is_bvh ? 1u : 0u;
+        const bool wanted = build_env ? strcmp(build_env, "device") == 0 : desc->n_prims >= (1u << 17);
+        fl.device_build = wanted && fl.static_scene && !reference_layout && n_bvh == 1 && !(wide_switch && atoi(wide_switch) == 1) &&
+                          rt_device_count() > 0;
+    }
     std::vector<DItem> items;
     for (uint32_t i = 0; i < desc->n_items; ++i) {
         const rt_item_desc &it = desc->items[i];
@@ -1245,8 +1334,25 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     // the winning leaf and skips behind the best hit without consulting flags (k_render's DEFER), on
     // a tree whose leaves are single spheres.  RTIOW_STATIC_VARIANT=0 keeps the general variant and
     // the reference's leaves (tests, A/B).
-    const bool static_scene = fl.static_scene && !fl.nodes.empty();
-    if (static_scene) fl.split_pairs(items);   // (what re-clustering left whole: the reference layout's leaves)
+    const bool on_device = fl.device_build && fl.device_refs.size() >= 2;
+    size_t n_nodes = fl.nodes.size();
+    if (on_device) {
+        // the spheres go up first; the tree is built over them where they are
+        hipError_t e = s->prims.upload(fl.prims.data(), fl.prims.size());
+        n_nodes = fl.device_refs.size() - 1;
+        if (e == hipSuccess) e = s->nodes.alloc(n_nodes);
+        uint32_t depth = 0;
+        if (e == hipSuccess)
+            e = lbvh::build(s->prims.p, fl.device_refs.data(), (uint32_t)fl.device_refs.size(), fl.far_allowance, fl.device_lo, fl.device_hi, s->nodes.p, 0, &depth);
+        if (e != hipSuccess) return fail(RT_E_DEVICE, "tree build on the device: %s", hipGetErrorString(e));
+        fl.max_depth = std::max(fl.max_depth, depth);
+        lap("tree built on the device");
+    }
+    const bool static_scene = fl.static_scene && n_nodes > 0;
+    if (static_scene && !on_device) {
+        fl.split_pairs(items);   // (what re-clustering left whole: the reference layout's leaves)
+        n_nodes = fl.nodes.size();
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
@@ -1269,7 +1375,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         size_t sums = kSumsLdsTree;
         const size_t leaf_bytes = fl.leaf_boxes.size() * (static_scene ? SLEAF_STRIDE : LLEAF_STRIDE);
         auto whole_tree = [&](int waves) {
-            return kHeadLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((fl.nodes.size() * LNODE_STRIDE + 7) & ~(size_t)7) + leaf_bytes;
+            return kHeadLds + 4 * waves * sums + (size_t)stack_depth * 256 * waves * sizeof(int) + ((n_nodes * LNODE_STRIDE + 7) & ~(size_t)7) + leaf_bytes;
         };
         // the four-wide tree whole in LDS, with `cap` stack entries per lane there
         auto whole_tree4 = [&](int waves, uint32_t cap) {
@@ -1299,7 +1405,7 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             s->render_stack_cap = cap4;
             s->render_lds_bytes = whole_tree4(waves4, cap4);
             if (stack_depth4 > cap4) spill_ints = (size_t)(stack_depth4 - cap4) * s->n_cus * 256 * waves4;
-        } else if (whole <= kLdsBudget && !force_nodes) {
+        } else if (whole <= kLdsBudget && !force_nodes && !on_device) {
             s->render_lds_tree = true;
             s->render_waves = waves_fit;
             s->render_lnodes = (uint32_t)fl.nodes.size();
@@ -1326,7 +1432,8 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             const size_t base = kHeadLds + 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
             size_t k = std::min(fl.nodes.size(), (kLdsBudget - base - 8) / LNODE_STRIDE);
             if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
-            fl.stage_top_levels(k, items);
+            // (a tree built on the device stays there: no node is staged, which measures within noise of staging)
+            if (!on_device) fl.stage_top_levels(k, items);
             s->render_lnodes = (uint32_t)k;
             s->render_stack_cap = cap;
             s->render_lds_bytes = base + ((k * LNODE_STRIDE + 7) & ~(size_t)7);
@@ -1340,26 +1447,31 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     s->material_of_prim.resize(desc->n_prims);
     for (uint32_t i = 0; i < desc->n_prims; ++i) s->material_of_prim[i] = desc->prims[i].material;
 
+    const int table_slices = (desc->n_materials >= (1u << 16) || desc->n_textures >= (1u << 16)) ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
     std::vector<DMat> mats(desc->n_materials);
-    for (uint32_t i = 0; i < desc->n_materials; ++i) {
-        const rt_material_desc &m = desc->materials[i];
-        DMat d;
-        memset(&d, 0, sizeof d);
-        d.kind = m.kind; d.tex = m.texture; d.fuzz = m.fuzziness; d.ri = m.refractive_index;
-        d.inv_ri = 1 / d.ri;
-        { const double r0 = (1 - d.ri) / (1 + d.ri); d.r0sq = r0 * r0; }
-        for (int k = 0; k < 3; ++k) d.albedo[k] = m.albedo[k];
-        mats[i] = d;
-    }
+    flattener::for_slices(0, desc->n_materials, table_slices, [&](size_t b0, size_t b1, int) {
+        for (size_t i = b0; i < b1; ++i) {
+            const rt_material_desc &m = desc->materials[i];
+            DMat d;
+            memset(&d, 0, sizeof d);
+            d.kind = m.kind; d.tex = m.texture; d.fuzz = m.fuzziness; d.ri = m.refractive_index;
+            d.inv_ri = 1 / d.ri;
+            { const double r0 = (1 - d.ri) / (1 + d.ri); d.r0sq = r0 * r0; }
+            for (int k = 0; k < 3; ++k) d.albedo[k] = m.albedo[k];
+            mats[i] = d;
+        }
+    });
     std::vector<DTex> texs(desc->n_textures);
-    for (uint32_t i = 0; i < desc->n_textures; ++i) {
-        const rt_texture_desc &t = desc->textures[i];
-        DTex d;
-        memset(&d, 0, sizeof d);
-        d.kind = t.kind; d.even = t.even; d.odd = t.odd;
-        for (int k = 0; k < 3; ++k) d.c[k] = t.colour[k];
-        texs[i] = d;
-    }
+    flattener::for_slices(0, desc->n_textures, table_slices, [&](size_t b0, size_t b1, int) {
+        for (size_t i = b0; i < b1; ++i) {
+            const rt_texture_desc &t = desc->textures[i];
+            DTex d;
+            memset(&d, 0, sizeof d);
+            d.kind = t.kind; d.even = t.even; d.odd = t.odd;
+            for (int k = 0; k < 3; ++k) d.c[k] = t.colour[k];
+            texs[i] = d;
+        }
+    });
     std::vector<double> ranfloat(256, 0.0);
     std::vector<uint8_t> perm(768, 0);
     if (desc->perlin_ranfloat && desc->perlin_perm_x && desc->perlin_perm_y && desc->perlin_perm_z) {
@@ -1375,10 +1487,10 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         if (int rc = scratch_on_device(device, &unused)) return rc;
     }
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
+    if (e == hipSuccess && !on_device) e = s->nodes.upload(fl.nodes.data(), fl.nodes.size());
     if (e == hipSuccess && s->render_wide) e = s->nodes4.upload(fl.nodes4.data(), fl.nodes4.size());
     if (e == hipSuccess) e = s->leaves.upload(fl.leaf_boxes.data(), fl.leaf_boxes.size());
-    if (e == hipSuccess) e = s->prims.upload(fl.prims.data(), fl.prims.size());
+    if (e == hipSuccess && !on_device) e = s->prims.upload(fl.prims.data(), fl.prims.size());
     if (e == hipSuccess) e = s->items.upload(items.data(), items.size());
     if (e == hipSuccess) e = s->mats.upload(mats.data(), mats.size());
     if (e == hipSuccess) e = s->texs.upload(texs.data(), texs.size());
@@ -1482,12 +1594,12 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
         if (!std::isfinite(f.h) || !std::isfinite(f.cx) || !std::isfinite(f.cy) || !std::isfinite(f.cz)) { f.cx = f.cy = f.cz = 0; f.h = HUGE_VALF; }
     }
     s->lds_bytes = (size_t)s->d.stack_depth * kBlock * sizeof(int);
-    s->n_nodes_dev = (uint32_t)fl.nodes.size();
+    s->n_nodes_dev = (uint32_t)n_nodes;
     s->n_prims_dev = (uint32_t)fl.prims.size();
     if (getenv("RTIOW_VERBOSE"))
         fprintf(stderr, "rtiow: %zu nodes, %zu spheres, tree depth %u, %s layout; render kernel: %s, %u nodes and %u leaves in LDS, "
                         "%u stack entries in LDS, %zu B of LDS (budget %zu), %zu B of spill, leaf boxes tested %s\n",
-                fl.nodes.size(), (size_t)desc->n_prims, fl.max_depth, reference_layout ? "reference" : "re-clustered",
+                n_nodes, (size_t)desc->n_prims, fl.max_depth, reference_layout ? "reference" : (on_device ? "built on the device" : "re-clustered"),
                 s->render_wide ? (s->render_lds_tree ? (s->render_waves == kWavesMax ? "four-wide tree whole in LDS, 1024 threads" : "four-wide tree whole in LDS, 768 threads") : "four-wide tree in device memory, 1024 threads")
                                : s->render_lds_tree ? (s->render_waves == kWavesMax ? "whole tree in LDS, 1024 threads" : "whole tree in LDS, 768 threads") : "top levels in LDS, 1024 threads",
                 s->render_lnodes, s->render_lleaves,

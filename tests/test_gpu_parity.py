@@ -610,6 +610,44 @@ def test_postponed_leaf_box_tests_change_nothing(rt, orc, scene, monkeypatch):
     np.testing.assert_allclose(frames[0][0], exp, rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("scene", ["book1", "stress4096", "ties"])
+def test_tree_built_on_the_device_changes_nothing(rt, orc, scene, monkeypatch, capfd):
+    # RTIOW_BUILD=device: the tree over a static scene's spheres is a linear BVH built by the GPU (Morton
+    # codes of the centres, radix sort, one thread per inner node, boxes bottom-up) instead of the host's
+    # surface-area clustering.  Another tree over the same leaves: object::hit and the frames must not move
+    # a bit, whatever the shape -- coincident centres (equal codes) included -- and equal the oracle's.
+    # (Large scenes take this path by default: test_million_sphere_tree.)
+    rng = np.random.default_rng(17)
+    n = 30000
+    o = rng.uniform(-1, 1, (n, 3)) * [30, 6, 30] + [0, 3, 0]
+    tgt = rng.uniform(-1, 1, (n, 3)) * [12, 0.5, 12]
+    rays = np.hstack([o, (tgt - o) * rng.uniform(0.1, 3, (n, 1)), rng.uniform(-1, 1, (n, 1))])
+    cam15 = np.array(golden("frames")["camera"])
+    cam15[10] = 2.0
+    monkeypatch.setenv("RTIOW_VERBOSE", "1")
+    got = []
+    for build in ("host", "device"):
+        monkeypatch.setenv("RTIOW_BUILD", build)
+        capfd.readouterr()
+        w = rt.World(recipe(scene))
+        said = capfd.readouterr().err
+        assert ("built on the device" in said) == (build == "device"), said
+        try:
+            got.append((w.trace(rays, 0.001, np.finfo(np.float64).max), w.render(rt.camera(cam15), 72, 36, 0, 5, 33), w.render(rt.camera(cam15), 72, 36, 0, 40, 33)))
+        finally:
+            w.close()
+    (ha, fa, da), (hb, fb, db) = got
+    for field in ("hit", "prim", "t", "p", "normal"):
+        assert np.array_equal(ha[field], hb[field]), field
+    assert np.array_equal(fa[0], fb[0]) and fa[1].rays == fb[1].rays
+    assert np.array_equal(da[0], db[0]) and da[1].rays == db[1].rays
+    hit, prim, tpn = orc.Scene(recipe(scene)).trace(rays, 0.001, np.finfo(np.float64).max)
+    assert np.array_equal(hb["hit"], hit.astype(np.int32)) and np.array_equal(hb["prim"], prim)
+    exp, counters = orc.Scene(recipe(scene)).render(cam15, 72, 36, 0, 5, 33, orc.ORC_RNG_STREAM)
+    assert fb[1].rays == counters.rays
+    np.testing.assert_allclose(fb[0], exp, rtol=1e-11, atol=1e-13)
+
+
 @pytest.mark.parametrize("scene", ["book1", "stress4096", "ties", "lists_static"])
 def test_four_wide_walk_changes_nothing(rt, orc, scene, monkeypatch, tmp_path, capfd):
     # RTIOW_WIDE=1: scenes without moving spheres walk a tree of four-child nodes (every other level of

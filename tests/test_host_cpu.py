@@ -65,6 +65,25 @@ def test_parallel_bvh_build_equals_serial_build(rt, orc, tmp_path, monkeypatch):
     parallel, _ = rt.world_tables(path)
     assert np.array_equal(serial, parallel) and len(serial) > 60000
     assert np.array_equal(serial, orc.Scene(path).nodes())   # = the oracle's restatement of bvh_node.cpp:8-50
+    # groups this large are split by selection instead of the reference's sorts where the keys decide every split
+    # (they do here: random coordinates); RTIOW_BUILD_ARRANGE=0 takes the sorts: the same tree
+    monkeypatch.setenv("RTIOW_BUILD_ARRANGE", "0")
+    sorted_build, _ = rt.world_tables(path)
+    assert np.array_equal(sorted_build, parallel)
+
+
+def test_large_group_with_equal_keys_takes_the_references_sorts(rt, orc, tmp_path):
+    # 70 225 spheres on a lattice: box minima coincide by the hundred, the order an unstable sort leaves equal
+    # keys in decides which sphere lands in which half, and only the reference's own algorithm on the
+    # reference's own sequence reproduces that (bvh_node.cpp:9-29 over libstdc++'s introsort).  The selection
+    # shortcut must notice and stand aside.
+    lines = ["rtiow-recipe 1", "texture constant 0.5 0.5 0.5", "material lambertian 0", "bvh_begin 11 0 1"]
+    lines += [f"sphere 0 {i} 0.3 {j} 0.3" for i in range(265) for j in range(265)]
+    lines.append("bvh_end")
+    path = tmp_path / "lattice.recipe"
+    path.write_text("\n".join(lines) + "\n")
+    nodes, _ = rt.world_tables(str(path))
+    assert len(nodes) > 65536 and np.array_equal(nodes, orc.Scene(str(path)).nodes())
 
 
 def test_perlin_tables_match_reference_sequence(rt, orc):
