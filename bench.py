@@ -322,20 +322,31 @@ def extra_configs(ranks, rt, main_world, rank, local_rank):
                  ("c2 at 16 spp", "book1", 1920, 1080, 16, None, "book", 2),
                  ("c3: book-2 scene, moving spheres", "book2", 1920, 1080, 1024, None, "book", 2),
                  ("c4 frame on one GPU: 3840x2160 at 512 spp (one GPU's share of 4096 split over 8)", "book1", 3840, 2160, 512, None, "book", 2),
-                 ("c5: 10^6 spheres, 64 spp", "stress:1000000", 1920, 1080, 64, None, c5cam, 2),
-                 ("c5: 10^6 spheres, 8 spp (one GPU's share of 64 split over 8)", "stress:1000000", 1920, 1080, 8, None, c5cam, 2)]
+                 ("c5: 10^6 spheres, 64 spp (tree over the spheres built on the GPU: the default for large scenes)", "stress:1000000", 1920, 1080, 64, None, c5cam, 2),
+                 ("c5: 10^6 spheres, 8 spp (one GPU's share of 64 split over 8)", "stress:1000000", 1920, 1080, 8, None, c5cam, 2),
+                 ("c5: 10^6 spheres, 64 spp, tree built on the host (RTIOW_BUILD=host: surface-area clustering)", "stress:1000000@host", 1920, 1080, 64, None, c5cam, 2)]
     out = []
-    worlds = {"book1": (main_world, None)}
+    worlds = {("book1", None): (main_world, None)}
     counts = {}
     for name, scene, nx, ny, spp, total_spp, cam_spec, steps in cases:
-        if scene not in worlds:
+        build = None
+        if "@" in scene:                         # scene@host / scene@device: where the tree over the spheres is built
+            scene, build = scene.split("@")
+        key = (scene, build)
+        if key not in worlds and (scene, None) in worlds and build is None:
+            key = (scene, None)
+        if key not in worlds:
+            if build:
+                os.environ["RTIOW_BUILD"] = build
             t0 = time.perf_counter()
             if scene.startswith("stress:"):      # generated in memory: scene API objects -> reference BVH build -> layout -> upload
                 w_new = rt.World(None, device=local_rank, generator=("stress", 1, int(scene.split(":")[1])))
             else:
                 w_new = rt.World(scene_file(rt, scene), device=local_rank)
-            worlds[scene] = (w_new, dict(w_new.setup_seconds(), total_s=time.perf_counter() - t0))
-        w, setup = worlds[scene]
+            worlds[key] = (w_new, dict(w_new.setup_seconds(), total_s=time.perf_counter() - t0))
+            if build:
+                del os.environ["RTIOW_BUILD"]
+        w, setup = worlds[key]
         rec = run_config(ranks, rt, w, rank, name, scene, nx, ny, cam_spec, spp, total_spp, steps, 1, setup)
         if rank == 0 and ranks.world == 1:
             if (scene, cam_spec) not in counts:
@@ -344,9 +355,9 @@ def extra_configs(ranks, rt, main_world, rank, local_rank):
                 if scene.startswith("stress:"):
                     os.unlink(path)
             b, e = rec["sample_range"]
-            rec["roofline"] = roofline(f"{scene} {nx}x{ny} samples [{b},{e})", counts[(scene, cam_spec)], nx * ny * (e - b), e - b, rec["kernel_ms_steps"])
+            rec["roofline"] = roofline(f"{scene}{'@' + build if build else ''} {nx}x{ny} samples [{b},{e})", counts[(scene, cam_spec)], nx * ny * (e - b), e - b, rec["kernel_ms_steps"])
         out.append(rec)
-    for scene, (w, setup) in worlds.items():
+    for w, setup in worlds.values():
         if setup is not None:
             w.close()
     return out

@@ -157,6 +157,28 @@ __global__ __launch_bounds__(kBuildBlock) void k_depth(const int *parent_inner, 
     atomicMax(deepest, d);
 }
 
+// Copies the top of the tree, breadth-first from `root`, into nodes[0, k): the part the render kernel keeps
+// in LDS (its nodes are the first k of the table).  A copy's children that were copied too are referred to
+// by their new numbers, the others by their old ones; the originals stay where they are, unreferenced.
+// One lane: a thousand nodes, each a dependent 64-byte read.
+constexpr uint32_t kStageMax = 4096;
+__global__ void k_stage_top(DNode *nodes, uint32_t k, int32_t root) {
+    __shared__ int32_t queue[kStageMax];
+    if (threadIdx.x != 0 || blockIdx.x != 0 || k == 0) return;
+    uint32_t count = 1;
+    queue[0] = root;
+    for (uint32_t head = 0; head < count; ++head) {
+        DNode nd = nodes[queue[head]];
+        for (int c = 0; c < 2; ++c) {
+            if (nd.child[c] >= 0 && count < k) {
+                queue[count] = nd.child[c];
+                nd.child[c] = (int32_t)count++;
+            }
+        }
+        nodes[head] = nd;
+    }
+}
+
 struct scratch {   // freed when the build ends, whichever way
     void *p[16] = {};
     int used = 0;
@@ -171,10 +193,15 @@ struct scratch {   // freed when the build ends, whichever way
 };
 
 // Builds the tree over the n >= 2 single spheres `refs` (host array; leaf references into d_prims, which
-// is already on the current device) into d_nodes[0, n - 1) (device memory of the caller's); the root is
-// node 0, written as first_index.  Returns the HIP error of the first call that failed.
+// is already on the current device) into d_nodes[staged, staged + n - 1) (device memory of the caller's:
+// staged + n - 1 nodes), node j of the build being number staged + j of the table, and copies the top
+// `staged` nodes (as many as the tree has, at most) to its front, breadth-first: the walk starts at node 0.
+// *staged_out is the number copied.  Returns the HIP error of the first call that failed.
 inline hipError_t build(const DPrim *d_prims, const int32_t *refs, uint32_t n, double far_allowance, const double centre_lo[3],
-                        const double centre_hi[3], DNode *d_nodes, int32_t first_index, uint32_t *depth_out) {
+                        const double centre_hi[3], DNode *d_table, uint32_t staged, uint32_t *depth_out) {
+    if (staged > kStageMax) staged = kStageMax;
+    DNode *const d_nodes = d_table + staged;
+    const int32_t first_index = (int32_t)staged;
     scratch mem;
     int32_t *d_refs;
     double *d_boxes, *d_node_boxes;
@@ -215,6 +242,8 @@ inline hipError_t build(const DPrim *d_prims, const int32_t *refs, uint32_t n, d
     hipLaunchKernelGGL(k_fit, dim3(blocks), dim3(kBuildBlock), 0, 0, d_boxes, d_order_sorted, d_refs, d_children, d_parent_inner, d_parent_leaf, (int)n,
                        d_counters, d_node_boxes, d_nodes, first_index);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(kBuildBlock), 0, 0, d_parent_inner, d_parent_leaf, (int)n, d_counters + n);
+    // (a tree of fewer nodes than places: every node is copied, the places left over stay unused)
+    if (staged) hipLaunchKernelGGL(k_stage_top, dim3(1), dim3(64), 0, 0, d_table, staged < n - 1 ? staged : n - 1, first_index);
     LBVH_TRY(hipGetLastError());
     unsigned int deepest = 0;
     LBVH_TRY(hipMemcpy(&deepest, d_counters + n, sizeof deepest, hipMemcpyDeviceToHost));   // (waits for the kernels)

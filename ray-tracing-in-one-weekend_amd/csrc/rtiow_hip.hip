@@ -1336,14 +1336,22 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     // the reference's leaves (tests, A/B).
     const bool on_device = fl.device_build && fl.device_refs.size() >= 2;
     size_t n_nodes = fl.nodes.size();
+    uint32_t staged_on_device = 0;
     if (on_device) {
-        // the spheres go up first; the tree is built over them where they are
+        // the spheres go up first; the tree is built over them where they are.  The table's first entries are
+        // copies of the tree's top levels, breadth-first: what the render kernel keeps in LDS beside a
+        // twelve-entry stack per lane (a large tree is deeper than that).
         hipError_t e = s->prims.upload(fl.prims.data(), fl.prims.size());
-        n_nodes = fl.device_refs.size() - 1;
+        const size_t tree_nodes = fl.device_refs.size() - 1;
+        const size_t beside = kHeadLds + 4 * kWavesMax * 3072 + (size_t)kSpillStackCap * 256 * kWavesMax * sizeof(int);
+        size_t room = std::min<size_t>({tree_nodes, (kLdsBudget - beside - 8) / LNODE_STRIDE, (size_t)lbvh::kStageMax});
+        if (const char *f = getenv("RTIOW_RENDER_LDS_NODES")) room = std::min(room, (size_t)std::max(0, atoi(f)));
+        staged_on_device = (uint32_t)room;
+        n_nodes = staged_on_device + tree_nodes;
         if (e == hipSuccess) e = s->nodes.alloc(n_nodes);
         uint32_t depth = 0;
         if (e == hipSuccess)
-            e = lbvh::build(s->prims.p, fl.device_refs.data(), (uint32_t)fl.device_refs.size(), fl.far_allowance, fl.device_lo, fl.device_hi, s->nodes.p, 0, &depth);
+            e = lbvh::build(s->prims.p, fl.device_refs.data(), (uint32_t)fl.device_refs.size(), fl.far_allowance, fl.device_lo, fl.device_hi, s->nodes.p, staged_on_device, &depth);
         if (e != hipSuccess) return fail(RT_E_DEVICE, "tree build on the device: %s", hipGetErrorString(e));
         fl.max_depth = std::max(fl.max_depth, depth);
         lap("tree built on the device");
@@ -1432,8 +1440,9 @@ static int scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             const size_t base = kHeadLds + 4 * kWavesMax * sums + (size_t)cap * 256 * kWavesMax * sizeof(int);
             size_t k = std::min(fl.nodes.size(), (kLdsBudget - base - 8) / LNODE_STRIDE);
             if (force_nodes) k = std::min(k, (size_t)std::max(0, atoi(force_nodes)));
-            // (a tree built on the device stays there: no node is staged, which measures within noise of staging)
+            // (a tree built on the device has its top levels in front already)
             if (!on_device) fl.stage_top_levels(k, items);
+            else k = std::min<size_t>(staged_on_device, (kLdsBudget - base - 8) / LNODE_STRIDE);
             s->render_lnodes = (uint32_t)k;
             s->render_stack_cap = cap;
             s->render_lds_bytes = base + ((k * LNODE_STRIDE + 7) & ~(size_t)7);
