@@ -564,23 +564,30 @@ void orc_texture_value(const oscene *s, int tex, ovec3 p, double out[3]) {
 /* material.cpp:35-40, distribution {-1,1} (material.cpp:42) */
 static ovec3 random_in_unit_sphere(orng *g) {
     if (g->kind == ORC_RNG_STREAM) {
-        /* The per-path stream of the GPU library (rt_device.hpp, StreamRng::in_unit_sphere): the same
-         * points with the same probabilities, but an attempt first draws the top 32 bits of each
-         * coordinate and is rejected on those alone when no low bits could bring it inside. */
-        for (;;) {
-            double cx, cy, cz;
-            do {
-                cx = (double)orc_stream_next(&g->st) * 0x1p-31 - 1.0;
-                cy = (double)orc_stream_next(&g->st) * 0x1p-31 - 1.0;
-                cz = (double)orc_stream_next(&g->st) * 0x1p-31 - 1.0;
-            } while (!(cx * cx + cy * cy + cz * cz < 1.0 + 0x1p-28));
-            uint32_t l1 = orc_stream_next(&g->st), l2 = orc_stream_next(&g->st);
-            ovec3 c;
-            c.x = cx + (double)(l1 >> 11) * 0x1p-52;
-            c.y = cy + (double)(l2 >> 11) * 0x1p-52;
-            c.z = cz + (double)(((l1 & 0x7FFu) << 10) | ((l2 & 0x7FFu) >> 1)) * 0x1p-52;
-            if (c.x * c.x + c.y * c.y + c.z * c.z < 1) return c;
-        }
+        /* The per-path stream of the GPU library (rt_device.hpp, StreamRng::in_unit_sphere), operation for
+         * operation: a point uniform in the unit sphere without rejection.  Direction: two outputs give a
+         * point of the square [-1, 1]^2 (24 bits each), mapped onto the sphere by the equal-area octahedral
+         * map (Clarberg 2008) in single precision; radius: the largest of three 32-bit uniforms (density
+         * 3 r^2), shortened by 2^-21 so that the rounding of the direction cannot carry the point outside.
+         * Every operation is a correctly rounded IEEE one on both sides (this file is built with
+         * -ffp-contract=off). */
+        const uint32_t ha = orc_stream_next(&g->st), hb = orc_stream_next(&g->st);
+        const float a = fmaf((float)(ha >> 8), 0x1p-23f, 0x1p-24f - 1.0f), b = fmaf((float)(hb >> 8), 0x1p-23f, 0x1p-24f - 1.0f);
+        const float aa = fabsf(a), ab = fabsf(b);
+        const float d = 1.0f - (aa + ab), r = 1.0f - fabsf(d);
+        const float th = (r > 0 ? (ab - aa) / r : 0.0f) * 0.78539816339744830962f, q = th * th;
+        const float f = r * sqrtf(fmaf(-r, r, 2.0f)) * 0.70710678118654752440f;
+        float cs = 2.4801587e-05f;
+        cs = fmaf(cs, q, -0.0013888889f); cs = fmaf(cs, q, 0.041666668f); cs = fmaf(cs, q, -0.5f); cs = fmaf(cs, q, 1.0f);
+        float sn = 2.7557319e-06f;
+        sn = fmaf(sn, q, -0.00019841270f); sn = fmaf(sn, q, 0.0083333333f); sn = fmaf(sn, q, -0.16666667f); sn = fmaf(sn * q, th, th);
+        const float fx = copysignf(f * (cs - sn), a), fy = copysignf(f * (cs + sn), b), fz = copysignf(fmaf(-r, r, 1.0f), d);
+        const uint32_t w0 = orc_stream_next(&g->st), w1 = orc_stream_next(&g->st), w2 = orc_stream_next(&g->st);
+        const uint32_t w = w0 > w1 ? (w0 > w2 ? w0 : w2) : (w1 > w2 ? w1 : w2);
+        const double rho = fma((double)w, 0x1p-32 * (1.0 - 0x1p-21), 0x1p-33);
+        ovec3 c;
+        c.x = (double)fx * rho; c.y = (double)fy * rho; c.z = (double)fz * rho;
+        return c;
     }
     for (;;) {
         ovec3 c;

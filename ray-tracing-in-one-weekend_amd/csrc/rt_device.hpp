@@ -330,29 +330,44 @@ struct StreamRng {
     // result may be skipped (see camera_ray)
     static constexpr bool kMaySkipDeadDraws = true;
 
-    // material.cpp:35-40 over this stream: a point of the cube [-1, 1)^3, each coordinate k 2^-52 - 1
-    // with a uniform 53-bit k as symmetric() yields it, redrawn until it lies inside the unit sphere.
-    // The low 21 bits of the three k cannot change the verdict on a point whose coarse version
-    // (the top 32 bits, X = h 2^-31 - 1) is at |X|^2 >= 1 + 2^-28: the full point is farther from the
-    // coarse one than 6 2^-31 in |.|^2 by less.  Such attempts are rejected on three generator steps
-    // instead of six; only an attempt that may pass draws its low bits (two more steps) and takes the
-    // reference's test on the full point.  Which points come out, and how often, is unchanged.
-    __device__ __forceinline__ static double coarse(uint32_t h) {
-        const double x1 = __hiloint2double((int)(0x3FF00000u | (h >> 12)), (int)(h << 20));   // 1 + h 2^-32
-        return __builtin_fma(x1, 2.0, -3.0);                                                  // exact
+    // The correctly rounded single-precision square root of x in [1, 4): the hardware's v_sqrt_f32 is good to
+    // one unit in the last place; its neighbours are tried against x by the sign of an exactly computed
+    // residual (s_down s < x <= s s_up brackets the rounding boundaries: between s_down s and the square of
+    // the midpoint lies no single-precision number).
+    __device__ __forceinline__ static float sqrt_rounded(float x) {
+        float s = __builtin_amdgcn_sqrtf(x);
+        const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+        const float below_x = __builtin_fmaf(-down, s, x), above_x = __builtin_fmaf(-up, s, x);
+        if (below_x <= 0.0f) s = down;
+        if (above_x > 0.0f) s = up;
+        return s;
     }
+
+    // material.cpp:35-40 asks for a point uniform in the unit sphere and gets it by rejection from the cube:
+    // 1.9 attempts on average, and a wave waits for its unluckiest lane (6.5 attempts).  A path's own stream
+    // owes nobody a particular way of spending its outputs, only the distribution:
     __device__ __forceinline__ void in_unit_sphere(double &x, double &y, double &z) {
-        for (;;) {
-            double cx, cy, cz;
-            do {
-                cx = coarse(next()); cy = coarse(next()); cz = coarse(next());
-            } while (!(cx * cx + cy * cy + cz * cz < 1.0 + 0x1p-28));
-            const uint32_t l1 = next(), l2 = next();
-            x = __builtin_fma((double)(l1 >> 11), 0x1p-52, cx);   // exact: 53 bits in all
-            y = __builtin_fma((double)(l2 >> 11), 0x1p-52, cy);
-            z = __builtin_fma((double)(((l1 & 0x7FFu) << 10) | ((l2 & 0x7FFu) >> 1)), 0x1p-52, cz);
-            if (x * x + y * y + z * z < 1) return;
-        }
+        // no rejection: the direction by the equal-area octahedral map of the square onto the sphere (Clarberg,
+        // "Fast equal-area mapping of the (hemi)sphere using SIMD", 2008) in single precision -- 24 bits per
+        // coordinate of the square, a unit vector to 2^-22 -- and the radius as the largest of three 32-bit
+        // uniforms (density 3 r^2), shortened by 2^-21 so that the point stays inside the unit sphere.  Five
+        // generator outputs, no loop, every operation correctly rounded (the oracle repeats them one for one).
+        const uint32_t ha = next(), hb = next();
+        const float a = __builtin_fmaf((float)(ha >> 8), 0x1p-23f, 0x1p-24f - 1.0f), b = __builtin_fmaf((float)(hb >> 8), 0x1p-23f, 0x1p-24f - 1.0f);   // exact
+        const float aa = __builtin_fabsf(a), ab = __builtin_fabsf(b);
+        const float d = 1.0f - (aa + ab), r = 1.0f - __builtin_fabsf(d);
+        const float th = (r > 0 ? __fdiv_rn(ab - aa, r) : 0.0f) * 0.78539816339744830962f, q = th * th;
+        const float f = r * sqrt_rounded(__builtin_fmaf(-r, r, 2.0f)) * 0.70710678118654752440f;   // (2 - r r lies in [1, 2])
+        // cos and sin of th, |th| <= pi/4 (Taylor polynomials: errors below 1e-7)
+        float c = 2.4801587e-05f;
+        c = __builtin_fmaf(c, q, -0.0013888889f); c = __builtin_fmaf(c, q, 0.041666668f); c = __builtin_fmaf(c, q, -0.5f); c = __builtin_fmaf(c, q, 1.0f);
+        float sn = 2.7557319e-06f;
+        sn = __builtin_fmaf(sn, q, -0.00019841270f); sn = __builtin_fmaf(sn, q, 0.0083333333f); sn = __builtin_fmaf(sn, q, -0.16666667f); sn = __builtin_fmaf(sn * q, th, th);
+        const float fx = __builtin_copysignf(f * (c - sn), a), fy = __builtin_copysignf(f * (c + sn), b), fz = __builtin_copysignf(__builtin_fmaf(-r, r, 1.0f), d);
+        const uint32_t w0 = next(), w1 = next(), w2 = next();
+        const uint32_t w = w0 > w1 ? (w0 > w2 ? w0 : w2) : (w1 > w2 ? w1 : w2);
+        const double rho = __builtin_fma((double)w, 0x1p-32 * (1.0 - 0x1p-21), 0x1p-33);
+        x = (double)fx * rho; y = (double)fy * rho; z = (double)fz * rho;
     }
 };
 

@@ -162,3 +162,17 @@ def test_division_by_a_shared_reciprocal_is_the_ieee_division():
     r = subprocess.run([exe, "65536"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " mismatches 0" in r.stdout
+
+
+def test_unit_sphere_sampler_equals_the_oracles_point_for_point(orc, tmp_path):
+    # The per-path streams sample the unit sphere without rejection: octahedral map in single precision, a
+    # hardware square root corrected to the rounded one, IEEE division.  The oracle restates it in C; the two
+    # must agree in every bit of every coordinate (frames agree to 1e-11 only if they do).
+    exe = os.path.join(ROOT, "ray-tracing-in-one-weekend_amd", "csrc", "sampler_dump")
+    out = tmp_path / "points.bin"
+    lanes, n = 2048, 96
+    for seed, pixel0, sample in [(7, 1000, 3), (2 ** 63 + 5, 4000000000, 4095)]:
+        subprocess.run([exe, str(seed), str(pixel0), str(sample), str(lanes), str(n), str(out)], check=True, timeout=300)
+        got = np.fromfile(out).reshape(lanes, n, 3)
+        for i in range(0, lanes, 7):
+            assert np.array_equal(got[i], orc.stream_unit_sphere(seed, (pixel0 + i) % 2 ** 32, sample, n)), (seed, i)

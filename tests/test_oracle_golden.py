@@ -147,25 +147,38 @@ def test_stream_mode_matches_mt_mode_statistically(orc):
 
 
 def test_stream_unit_sphere_sampler_is_uniform_in_the_ball(orc):
-    # The per-path streams reject an attempt on the top 32 bits of its coordinates when the low bits
-    # could not bring it inside, and draw the low 21 bits only for attempts that may pass
-    # (material.cpp:35-40 is the loop it stands for).  The points must still be uniform over the
-    # 2^-52 grid inside the unit ball: inside, on the grid, radius^3 and every coordinate distributed
-    # as for the ball, low bits uniform and independent of the coarse part.
+    # material.cpp:35-40 draws points of the cube until one lies inside the unit sphere.  The per-path
+    # streams produce the same distribution without the loop: a direction by the equal-area octahedral
+    # map of two 24-bit uniforms, a radius as the largest of three 32-bit uniforms.  The points must be
+    # what the reference's are: strictly inside the unit sphere, radius^3 uniform, every coordinate with
+    # the ball's marginal, the direction uniform on the sphere (z and the azimuth uniform, octants equally
+    # filled) and independent of the radius.
     from scipy import stats
-    n = 400000
+    n = 1000000
     p = orc.stream_unit_sphere(7, 123, 45, n)
     r2 = (p * p).sum(axis=1)
     assert (r2 < 1).all() and r2.max() > 0.999
-    k = (p + 1.0) * 2.0 ** 52
-    assert np.array_equal(k, np.floor(k)) and k.min() >= 0 and k.max() < 2.0 ** 53
+    r = np.sqrt(r2)
     assert stats.kstest(r2 ** 1.5, "uniform").pvalue > 1e-3
     for a in range(3):
-        x = p[:, a]
-        assert stats.kstest(x, lambda t: (2 + 3 * t - t ** 3) / 4).pvalue > 1e-3
-        low = k[:, a].astype(np.int64) & (2 ** 21 - 1)
-        assert stats.kstest(low / 2.0 ** 21, "uniform").pvalue > 1e-3
-        assert abs(np.corrcoef(low, x)[0, 1]) < 0.01
-        counts = np.bincount(low & 15, minlength=16)
-        assert stats.chisquare(counts).pvalue > 1e-3
+        assert stats.kstest(p[:, a], lambda t: (2 + 3 * t - t ** 3) / 4).pvalue > 1e-3
+    u = p / r[:, None]
+    assert stats.kstest((u[:, 2] + 1) / 2, "uniform").pvalue > 1e-3
+    assert stats.kstest((np.arctan2(u[:, 1], u[:, 0]) + np.pi) / (2 * np.pi), "uniform").pvalue > 1e-3
+    octant = (u[:, 0] > 0) * 4 + (u[:, 1] > 0) * 2 + (u[:, 2] > 0)
+    assert stats.chisquare(np.bincount(octant, minlength=8)).pvalue > 1e-3
+    # a finer look at the sphere: 48 equal-area cells (6 bands in z x 8 sectors in azimuth)
+    cell = np.minimum((u[:, 2] + 1) * 3, 5).astype(int) * 8 + np.minimum((np.arctan2(u[:, 1], u[:, 0]) + np.pi) * (4 / np.pi), 7).astype(int)
+    assert stats.chisquare(np.bincount(cell, minlength=48)).pvalue > 1e-3
+    for a in range(3):
+        assert abs(np.corrcoef(r, u[:, a])[0, 1]) < 0.005 and abs(np.corrcoef(r, np.abs(u[:, a]))[0, 1]) < 0.005
+    # second moments of an isotropic ball: E[x^2] = 1/5, E[xy] = 0
+    assert np.allclose((p * p).mean(axis=0), 0.2, atol=2e-3) and abs((p[:, 0] * p[:, 2]).mean()) < 1e-3
+    # the same points from the reference's own loop over a generator of its own: two samples of one distribution
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-1, 1, (3 * n, 3))
+    q = q[(q * q).sum(axis=1) < 1][:n]
+    for a in range(3):
+        assert stats.ks_2samp(p[:, a], q[:, a]).pvalue > 1e-3
+    assert stats.ks_2samp(r, np.sqrt((q * q).sum(axis=1))).pvalue > 1e-3
     assert abs(np.corrcoef(p[:, 0], p[:, 1])[0, 1]) < 0.01 and abs(np.corrcoef(p[:, 1], p[:, 2])[0, 1]) < 0.01
