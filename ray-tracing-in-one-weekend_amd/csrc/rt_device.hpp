@@ -833,7 +833,16 @@ __device__ __forceinline__ bool world_closest_voted(const DScene &sc, const Tree
     // node steps taken on top of the one the wave voted for (measured: 485 static spheres 300.4 ms with 0,
     // 288.6 with 1, 285.9 with 2, 285.7 with 3, 283.5 with 4, 286.7 with 5; book-2 405 / 390 / 386 / 384 /
     // 387 with 4; 10^6 spheres 50.5 / 48.2 / 47.8 / 47.95 with 3)
-    constexpr int kExtraNodeSteps = LDS_TREE ? (DEFER ? 4 : 3) : 2;
+#ifndef RT_EXTRA_STATIC
+#define RT_EXTRA_STATIC 4
+#endif
+#ifndef RT_EXTRA_PAIRS
+#define RT_EXTRA_PAIRS 3
+#endif
+#ifndef RT_EXTRA_LARGE
+#define RT_EXTRA_LARGE 2
+#endif
+    constexpr int kExtraNodeSteps = LDS_TREE ? (DEFER ? RT_EXTRA_STATIC : RT_EXTRA_PAIRS) : RT_EXTRA_LARGE;
     const PlaneAddr pa = plane_addresses(tree.lnodes, r);
     const float tmin_below = below(tmin);
     double closest = tmax;
