@@ -343,7 +343,9 @@ def extra_configs(ranks, rt, main_world, rank, local_rank):
                 w_new = rt.World(None, device=local_rank, generator=("stress", 1, int(scene.split(":")[1])))
             else:
                 w_new = rt.World(scene_file(rt, scene), device=local_rank)
-            worlds[key] = (w_new, dict(w_new.setup_seconds(), total_s=time.perf_counter() - t0))
+            # (the first large world of a process also pays for its fresh heap pages: ~0.1-0.15 s for 10^6 spheres)
+            worlds[key] = (w_new, dict(w_new.setup_seconds(), total_s=time.perf_counter() - t0,
+                                       first_large_world_of_the_process=not any(k[0].startswith("stress:") for k in worlds)))
             if build:
                 del os.environ["RTIOW_BUILD"]
         w, setup = worlds[key]

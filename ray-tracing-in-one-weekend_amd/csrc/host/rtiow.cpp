@@ -5,6 +5,7 @@
 #include "rtiow.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <chrono>
 #include <cstdlib>
@@ -702,11 +703,19 @@ int32_t bvh_node::flatten_child(scene_flattener& out, aabb const&) const {
     // then appended with their references moved along.  Entry for entry what one thread writes (the tables
     // list a subtree's entries in the order of a left-to-right walk either way).
     bool split = false;
+    static std::atomic<int> helpers{0};   // threads flattening right halves at the moment, over all trees: at most 15
+    struct helper_slot {
+        bool taken;
+        helper_slot() : taken(helpers.fetch_add(1) < 15) { if (!taken) helpers.fetch_sub(1); }
+        ~helper_slot() { if (taken) helpers.fetch_sub(1); }
+    };
     if (n_objects >= kParallelFlatten && right != left) {
+        helper_slot const slot;
         scene_flattener local;
         int32_t r_local = 0;
         std::exception_ptr failed;
         try {
+            if (!slot.taken) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
             std::thread other([&] {
                 try { r_local = right->flatten_child(local, *box); } catch (...) { failed = std::current_exception(); }
             });
