@@ -1,0 +1,392 @@
+"""CPU tests of the checker for the Lisp tracer's features (oracle/onna_oracle.c) and of the product's host
+scene API (libonna_host.so): no GPU.
+
+The reference's Lisp tracer (onna/) has no tests, no fixtures and no rendered image, and no Lisp is installed
+here: PARITY UNPINNED.  What these tests pin instead are facts the Lisp text implies and that can be worked out
+by hand or by an independent route: closed-form hits, densities that integrate to one, estimators whose
+expectation is known, instances that commute with transforming the ray by hand.
+"""
+import ctypes
+import importlib
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+on = importlib.import_module("ray-tracing-in-one-weekend_amd.onna")
+import onna_oracle_lib as oo  # noqa: E402
+
+INF = float("inf")
+F = np.float32
+
+
+def rays_of(origins, directions, times=None):
+    o = np.asarray(origins, np.float64).reshape(-1, 3)
+    d = np.asarray(directions, np.float64).reshape(-1, 3)
+    t = np.zeros((len(o), 1)) if times is None else np.asarray(times, np.float64).reshape(-1, 1)
+    return np.hstack([o, d, t])
+
+
+def test_library_exports_what_the_header_declares():
+    header = open(os.path.join(ROOT, "include", "onna_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(on_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(on.HIP_SYMBOLS)
+    lib = on.hip()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_quad_hit_by_hand():
+    b = on.Builder()
+    q = b.quad([-1, -1, -2], [2, 0, 0], [0, 2, 0])
+    t = b.finish(q)
+    # straight down the -z axis from the origin, at (0.5, -0.25): t = 2, alpha = 0.75, beta = 0.375
+    h = oo.hit(t, t.desc.world, rays_of([[0.5, -0.25, 0]], [[0, 0, -1]]), 0.001, INF)[0]
+    assert h["hit"] == 1 and h["t"] == 2.0 and h["u"] == 0.75 and h["v"] == 0.375
+    assert list(h["p"]) == [0.5, -0.25, -2.0] and list(h["normal"]) == [0, 0, 1] and h["front_face"] == 1
+    # from behind: the same plane, the normal turned towards the ray
+    h = oo.hit(t, t.desc.world, rays_of([[0.5, -0.25, -4]], [[0, 0, 1]]), 0.001, INF)[0]
+    assert h["hit"] == 1 and h["t"] == 2.0 and list(h["normal"]) == [0, 0, -1] and h["front_face"] == 0
+    # outside the quad, parallel to it, beyond the interval: misses
+    miss = oo.hit(t, t.desc.world, rays_of([[1.5, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 0, -1], [1, 0, 0], [0, 0, -1]]), 0.001, 1.5)
+    assert not miss["hit"].any()
+    # the interval is closed for quads (interval-contains, scene.lisp:246), open for spheres (interval-surrounds, :174)
+    assert oo.hit(t, t.desc.world, rays_of([[0, 0, 0]], [[0, 0, -1]]), 0.001, 2.0)[0]["hit"] == 1
+    b2 = on.Builder()
+    s = b2.finish(b2.sphere([0, 0, -3], 1.0))
+    assert oo.hit(s, s.desc.world, rays_of([[0, 0, 0]], [[0, 0, -1]]), 0.001, 2.0)[0]["hit"] == 0
+    assert oo.hit(s, s.desc.world, rays_of([[0, 0, 0]], [[0, 0, -1]]), 0.001, 2.0000001)[0]["hit"] == 1
+
+
+def test_sphere_hit_and_texture_coordinates_by_hand():
+    b = on.Builder()
+    t = b.finish(b.sphere([0, 0, -3], 1.0))
+    h = oo.hit(t, t.desc.world, rays_of([[0, 0, 0]], [[0, 0, -2]]), 0.001, INF)[0]   # the direction is not normalised
+    assert h["t"] == 1.0 and list(h["p"]) == [0, 0, -2] and list(h["normal"]) == [0, 0, 1]
+    # u = (atan2(-z, x) + pi) / 2 pi with the outward normal (0, 0, 1): atan2(-1, 0) = -pi/2 -> 0.25; v = acos(-y) / pi = 0.5
+    assert h["u"] == 0.25 and h["v"] == 0.5
+    # from the inside the far root is taken and the normal turns
+    h = oo.hit(t, t.desc.world, rays_of([[0, 0, -3]], [[0, 1, 0]]), 0.001, INF)[0]
+    assert h["t"] == 1.0 and list(h["normal"]) == [0, -1, 0] and h["front_face"] == 0 and h["v"] == 1.0
+    # a moving sphere is where its centre ray is at the ray's time (scene.lisp:165)
+    b = on.Builder()
+    m = b.finish(b.sphere([0, 0, -3], 1.0, to=[0, 2, -3]))
+    h = oo.hit(m, m.desc.world, rays_of([[0, 1, 0]], [[0, 0, -1]], [0.5]), 0.001, INF)[0]
+    assert h["t"] == 2.0
+    assert oo.hit(m, m.desc.world, rays_of([[0, 2.5, 0]], [[0, 0, -1]], [0.0]), 0.001, INF)[0]["hit"] == 0
+
+
+def test_instances_commute_with_transforming_the_ray_by_hand():
+    rng = np.random.default_rng(5)
+    b = on.Builder()
+    box = b.box([0, 0, 0], [165, 330, 165])
+    moved = b.translate(b.rotate_y(box, 15.0), [265, 0, 295])
+    both = b.finish(b.list([box, moved]))
+    objs = both.objects()
+    kinds = objs["kind"]
+    i_box = int(np.nonzero(kinds == on.ON_OBJ_LIST)[0][0])
+    i_moved = int(np.nonzero(kinds == on.ON_OBJ_TRANSLATE)[0][0])
+    sn, cs = objs[np.nonzero(kinds == on.ON_OBJ_ROTATE_Y)[0][0]]["v"][:2]
+    assert sn == math.sin((15.0 * math.pi) / 180.0) and cs == math.cos((15.0 * math.pi) / 180.0)
+    o = rng.uniform(-200, 800, (4000, 3))
+    target = np.array([265, 0, 295]) + rng.uniform(-50, 250, (4000, 3))
+    d = target - o
+    got = oo.hit(both, i_moved, rays_of(o, d), 0.001, INF)
+    # by hand: translate the origin, rotate origin and direction (scene.lisp:329-330, 381-401)
+    o2 = o - np.array([265.0, 0, 295.0])
+    o3 = np.stack([cs * o2[:, 0] - sn * o2[:, 2], o2[:, 1], sn * o2[:, 0] + cs * o2[:, 2]], 1)
+    d3 = np.stack([cs * d[:, 0] - sn * d[:, 2], d[:, 1], sn * d[:, 0] + cs * d[:, 2]], 1)
+    plain = oo.hit(both, i_box, rays_of(o3, d3), 0.001, INF)
+    assert got["hit"].sum() > 1000
+    assert np.array_equal(got["hit"], plain["hit"]) and np.array_equal(got["t"], plain["t"]) and np.array_equal(got["object"], plain["object"])
+    m = got["hit"] == 1
+    p, n = plain["p"][m], plain["normal"][m]
+    back = np.stack([cs * p[:, 0] + sn * p[:, 2], p[:, 1], (-sn) * p[:, 0] + cs * p[:, 2]], 1) + np.array([265.0, 0, 295.0])
+    nback = np.stack([cs * n[:, 0] + sn * n[:, 2], n[:, 1], (-sn) * n[:, 0] + cs * n[:, 2]], 1)
+    assert np.array_equal(got["p"][m], back) and np.array_equal(got["normal"][m], nback)
+    assert np.array_equal(got["u"], plain["u"]) and np.array_equal(got["front_face"], plain["front_face"])
+
+
+def test_bounding_boxes_and_bvh_of_the_host_api():
+    t = on.Tables("bouncing-spheres", seed=11)
+    objs = t.objects()
+    n_spheres = int((objs["kind"] == on.ON_OBJ_SPHERE).sum())
+    assert 400 < n_spheres < 500
+    seen = np.zeros(len(objs), int)
+
+    def check(i, depth):
+        o = objs[i]
+        seen[i] += 1
+        if o["kind"] == on.ON_OBJ_SPHERE:
+            c0, dc, r = o["v"][0:3], o["v"][3:6], o["v"][6]
+            lo = np.minimum(c0 - r, c0 + dc - r)
+            hi = np.maximum(c0 + r, c0 + dc + r)
+            assert np.allclose(o["box"][0::2], lo, rtol=0, atol=1e-12) and np.allclose(o["box"][1::2], hi, rtol=0, atol=1e-12)
+            return 1, depth
+        assert o["kind"] == on.ON_OBJ_BVH
+        a, b = objs[o["a"]], objs[o["b"]]
+        # a node's box is the union of its children's (scene.lisp:56-59)
+        assert np.array_equal(o["box"][0::2], np.minimum(a["box"][0::2], b["box"][0::2]))
+        assert np.array_equal(o["box"][1::2], np.maximum(a["box"][1::2], b["box"][1::2]))
+        na, da = check(o["a"], depth + 1)
+        if o["a"] == o["b"]:
+            return na, da
+        nb, db = check(o["b"], depth + 1)
+        assert na == (na + nb) // 2 or na + nb <= 2   # (floor span 2) to the left (scene.lisp:72-74)
+        # sorted along the longest axis of the node's box (aabb.lisp:61-68): the left half's boxes start no later than the right half's
+        ext = o["box"][1::2] - o["box"][0::2]
+        axis = (0 if ext[0] > ext[2] else 2) if ext[0] > ext[1] else (1 if ext[1] > ext[2] else 2)
+        if a["kind"] == on.ON_OBJ_SPHERE and b["kind"] == on.ON_OBJ_SPHERE and na + nb > 2:
+            assert a["box"][2 * axis] <= b["box"][2 * axis]
+        return na + nb, max(da, db)
+
+    count, depth = check(t.desc.world, 0)
+    assert count == n_spheres and depth <= 10
+
+    c = on.Tables("cornell-box")
+    objs = c.objects()
+    assert len(objs) == 20 and c.desc.lights >= 0
+    rot = objs[objs["kind"] == on.ON_OBJ_ROTATE_Y][0]
+    tr = objs[objs["kind"] == on.ON_OBJ_TRANSLATE][0]
+    # the rotated box's corners by hand (scene.lisp:349-373)
+    sn, cs = rot["v"][0], rot["v"][1]
+    inner = objs[rot["a"]]["box"]   # the box's six quads, each padded where it is flat: a little more than 0..165
+    half = float(F(0.0001)) / 2
+    assert list(inner) == [-half, 165 + half, -half, 330 + half, -half, 165 + half]
+    xs = [cs * x + sn * z for x in inner[0:2] for z in inner[4:6]]
+    zs = [(-sn) * x + cs * z for x in inner[0:2] for z in inner[4:6]]
+    assert rot["box"][0] == min(xs) and rot["box"][1] == max(xs) and rot["box"][4] == min(zs) and rot["box"][5] == max(zs)
+    assert list(rot["box"][2:4]) == list(inner[2:4])
+    assert np.array_equal(tr["box"], rot["box"] + np.array([265.0, 265.0, 0, 0, 295.0, 295.0]))
+    # a quad is flat along one axis: padded to 0.0001 (a single-float literal, aabb.lisp:3-10)
+    quad = objs[objs["kind"] == on.ON_OBJ_QUAD][0]
+    assert quad["box"][1] - quad["box"][0] == pytest.approx(float(F(0.0001)), rel=1e-9)
+    assert quad["box"][0] == 555.0 - float(F(0.0001)) / 2
+
+
+def test_derived_quad_constants():
+    b = on.Builder()
+    t = b.finish(b.quad([1, 2, 3], [0, 0, -4], [0, 3, 0]))
+    v = t.objects()[0]["v"]
+    n = np.cross([0, 0, -4.0], [0, 3.0, 0])   # (12, 0, 0)
+    assert list(v[9:12]) == list(n * (1.0 / np.dot(n, n))) and list(v[12:15]) == [1, 0, 0] and v[15] == 1.0 and v[16] == 12.0
+
+
+def test_light_densities_integrate_to_one_and_match_their_samplers():
+    rng = np.random.default_rng(9)
+    b = on.Builder()
+    quad = b.quad([343, 554, 332], [-130, 0, 0], [0, 0, -105])
+    sphere = b.sphere([190, 90, 190], 90)
+    t = b.finish(b.list([quad, sphere]))
+    objs = t.objects()
+    i_list = t.desc.world
+    i_quad = int(np.nonzero(objs["kind"] == on.ON_OBJ_QUAD)[0][0])
+    i_sphere = int(np.nonzero(objs["kind"] == on.ON_OBJ_SPHERE)[0][0])
+    origin = np.array([278.0, 278.0, 278.0])
+    n = 400000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    od = np.hstack([np.tile(origin, (n, 1)), d * rng.uniform(0.5, 3.0, (n, 1))])   # the density does not depend on the direction's length
+    for obj in (i_quad, i_sphere, i_list):
+        p = oo.pdf_value(t, obj, od)
+        integral = p.mean() * 4 * math.pi
+        assert abs(integral - 1) < 4 * p.std() * 4 * math.pi / math.sqrt(n) + 1e-3, (obj, integral)
+    # the sampler's directions hit the object, and 1 / density averages to its solid angle (the quad's by the closed form of the density)
+    tape = rng.random((20000, 3))
+    for obj in (i_quad, i_sphere, i_list):
+        dirs = oo.random_direction(t, obj, np.tile(origin, (len(tape), 1)), tape)
+        p = oo.pdf_value(t, obj, np.hstack([np.tile(origin, (len(tape), 1)), dirs]))
+        assert (p > 0).mean() > 0.999
+    sphere_solid = 2 * math.pi * (1 - math.sqrt(1 - 90.0 ** 2 / np.dot(origin - [190, 90, 190], origin - [190, 90, 190])))
+    p = oo.pdf_value(t, i_sphere, np.hstack([origin, np.array([190, 90, 190]) - origin])[None, :])
+    assert p[0] == pytest.approx(1 / sphere_solid, rel=1e-14)
+
+
+def test_constant_medium_free_paths():
+    rng = np.random.default_rng(2)
+    b = on.Builder()
+    slab = b.box([-50, -50, -2], [50, 50, 0])
+    density = 0.7
+    t = b.finish(b.medium(slab, density, b.solid(1, 1, 1)))
+    n = 200000
+    u = rng.random((n, 2))
+    rays = rays_of(np.zeros((n, 3)) + [0, 0, 5], np.tile([0, 0, -0.5], (n, 1)))   # |d| = 0.5: distances are in world units (scene.lisp:438-444)
+    h = oo.hit(t, t.desc.world, rays, 0.001, INF, u)
+    frac = h["hit"].mean()
+    expect = 1 - math.exp(-density * 2.0)
+    assert abs(frac - expect) < 4 * math.sqrt(expect * (1 - expect) / n)
+    m = h["hit"] == 1
+    depth = (h["t"][m] - 10.0) * 0.5   # the slab is entered at t = 10
+    assert depth.min() >= 0 and depth.max() <= 2.0 + 1e-12
+    assert abs(depth.mean() - (1 / density - 2.0 * math.exp(-density * 2.0) / expect)) < 5 * depth.std() / math.sqrt(m.sum())
+    # exactly: t = 10 + (-1/density) log(u) / |d|
+    k = np.nonzero(m)[0][:100]
+    assert np.allclose(h["t"][k], 10.0 + (-1.0 / density) * np.log(u[k, 0]) / 0.5, rtol=1e-15)
+    # an occluder in front narrows the interval: hits only before it
+    h2 = oo.hit(t, t.desc.world, rays, 0.001, 11.0, u)
+    assert np.array_equal(h2["hit"], (h["hit"] == 1) & (h["t"] <= 11.0))
+    # a ray that starts inside the medium: the path inside starts at the interval's minimum (scene.lisp:434)
+    inside = oo.hit(t, t.desc.world, rays_of([[0, 0, -1]], [[0, 0, -1]]), 0.001, INF, np.array([[math.exp(-0.35)]]))[0]
+    assert inside["hit"] == 1 and inside["t"] == pytest.approx(0.001 + 0.5, rel=1e-14)
+
+
+def test_textures():
+    b = on.Builder()
+    even, odd = b.solid(0.2, 0.3, 0.1), b.solid(0.9, 0.9, 0.9)
+    cheq = b.chequer(0.32, even, odd)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    image = b.image(img)
+    noise = b.perlin(77, 4.0)
+    mats = [b.lambertian(x) for x in (cheq, image, noise)]
+    t = b.finish(b.list([b.sphere([0, 0, 0], 1, m) for m in mats]))
+    tex = t.textures()
+    i_cheq = int(np.nonzero(tex["kind"] == on.ON_TEX_CHEQUER)[0][0])
+    i_img = int(np.nonzero(tex["kind"] == on.ON_TEX_IMAGE)[0][0])
+    i_noise = int(np.nonzero(tex["kind"] == on.ON_TEX_PERLIN)[0][0])
+    assert tex[i_cheq]["scale"] == 1.0 / 0.32
+    p = rng.uniform(-3, 3, (5000, 3))
+    uvp = np.hstack([rng.random((5000, 2)), p])
+    got = oo.texture(t, i_cheq, uvp)
+    parity = np.floor((1.0 / 0.32) * p).sum(1) % 2 == 0
+    assert np.array_equal(got[:, 0], np.where(parity, 0.2, 0.9))
+    got = oo.texture(t, i_img, uvp)
+    i = np.minimum(np.floor(uvp[:, 0] * 5).astype(int), 4)
+    j = np.minimum(np.floor((1.0 - uvp[:, 1]) * 7).astype(int), 6)
+    assert np.array_equal(got, (img[j, i].astype(np.float64) / 256.0) ** 2)
+    edge = oo.texture(t, i_img, np.array([[1.0, 0.0, 0, 0, 0], [0.0, 1.0, 0, 0, 0]]))   # (one past the end in the Lisp: clamped)
+    assert np.array_equal(edge, (img[[6, 0], [4, 0]].astype(np.float64) / 256.0) ** 2)
+    # gradient noise vanishes at lattice points, so the marble there is 0.5 (1 + sin(scale z)) (texture.lisp:106-111)
+    lattice = rng.integers(-300, 300, (200, 3)).astype(np.float64)
+    got = oo.texture(t, i_noise, np.hstack([np.zeros((200, 2)), lattice]))
+    assert np.allclose(got[:, 0], 0.5 * (1 + np.sin(4.0 * lattice[:, 2])), rtol=0, atol=1e-15)
+    got = oo.texture(t, i_noise, uvp)
+    assert got.min() >= 0 and got.max() <= 1 and got.std() > 0.1 and np.array_equal(got[:, 0], got[:, 2])
+
+
+def test_camera_by_hand():
+    cam = on.make_camera(1.0, 600, 10, 50, (0, 0, 0), 40.0, (278, 278, -800), (278, 278, 0))
+    assert (cam.image_width, cam.image_height, cam.sqrt_spp, cam.max_depth) == (600, 600, 3, 50)
+    assert cam.recip_sqrt_spp == 1.0 / 3.0
+    h = math.tan(((40.0 * math.pi) / 180) / 2.0)
+    vh = (2.0 * h) * 10.0
+    assert list(cam.pixel_delta_u) == [-(1.0 * vh) * (1.0 / 600), 0.0, 0.0] or list(cam.pixel_delta_u)[0] == pytest.approx(-vh / 600, rel=1e-15)
+    assert cam.pixel_delta_v[1] == pytest.approx(-vh / 600, rel=1e-15)
+    # the middle of the image looks along the view direction
+    mid = np.array(cam.pixel00) + 299.5 * np.array(cam.pixel_delta_u) + 299.5 * np.array(cam.pixel_delta_v)
+    assert np.allclose(mid, [278, 278, -790], atol=1e-9)
+    # (round 400 16/9) = 225; ties go to even: 10 / 4 = 2.5 -> 2
+    assert on.make_camera(16 / 9, 400, 9, 10, (0, 0, 0), 90, (0, 0, 0), (0, 0, -1)).image_height == 225
+    assert on.make_camera(4.0, 10, 9, 10, (0, 0, 0), 90, (0, 0, 0), (0, 0, -1)).image_height == 2
+    # a sample's ray: through its stratum of its pixel, from the camera's centre when there is no defocus
+    r = oo.camera_ray(cam, 10, 20, 1, 2, 5, 20 * 600 + 10, 7)
+    assert list(r[:3]) == [278, 278, -800] and 0 <= r[6] < 1
+    at_plane = r[:3] + r[3:6]
+    fx = (at_plane[0] - cam.pixel00[0]) / cam.pixel_delta_u[0] - 10
+    fy = (at_plane[1] - cam.pixel00[1]) / cam.pixel_delta_v[1] - 20
+    assert 1 / 3 - 0.5 <= fx < 2 / 3 - 0.5 and 2 / 3 - 0.5 <= fy < 0.5
+
+
+def test_a_convex_lambertian_object_under_a_uniform_sky_shows_its_albedo():
+    # every scattered ray of a convex object leaves it: a sample is albedo * sky, and with the material's own
+    # density the weight scattering-pdf / pdf-value is exactly 1 (camera.lisp:118-130)
+    b = on.Builder()
+    t = b.finish(b.sphere([0, 0, -3], 1.0, b.lambertian(b.solid(0.25, 0.5, 0.75))))
+    cam = on.make_camera(1.0, 8, 16, 10, (1, 1, 1), 20.0, (0, 0, 0), (0, 0, -3))
+    sums, c = oo.render(t, cam, seed=4)
+    mean = sums / 16
+    assert np.allclose(mean[3:5, 3:5], [0.25, 0.5, 0.75], rtol=1e-14)
+    assert c.paths == 8 * 8 * 16
+    # with a list of lights the estimator changes, its expectation does not
+    b = on.Builder()
+    ball = b.sphere([0, 0, -3], 1.0, b.lambertian(b.solid(0.25, 0.5, 0.75)))
+    t2 = b.finish(ball, b.quad([-1, 3, -4], [2, 0, 0], [0, 0, 2]))
+    cam = on.make_camera(1.0, 8, 400, 10, (1, 1, 1), 20.0, (0, 0, 0), (0, 0, -3))
+    sums, _ = oo.render(t2, cam, seed=4)
+    mean = (sums / 400)[3:5, 3:5].mean(axis=(0, 1))
+    assert np.allclose(mean, [0.25, 0.5, 0.75], rtol=0.03)
+
+
+def test_an_emitter_is_seen_from_its_front_only_and_sample_ranges_add_up():
+    b = on.Builder()
+    light = b.diffuse_light(b.solid(4, 2, 1))
+    t = b.finish(b.quad([-1, -1, -2], [2, 0, 0], [0, 2, 0], light))   # normal +z: its front faces a camera at the origin
+    cam = on.make_camera(1.0, 4, 4, 5, (0, 0, 0), 40.0, (0, 0, 0), (0, 0, -2))
+    sums, _ = oo.render(t, cam, seed=1)
+    assert np.array_equal(sums[1:3, 1:3], np.tile([16.0, 8.0, 4.0], (2, 2, 1)))
+    back = on.make_camera(1.0, 4, 4, 5, (0, 0, 0), 40.0, (0, 0, -4), (0, 0, -2))
+    assert not oo.render(t, back, seed=1)[0].any()
+    c = on.Tables("cornell-box")
+    cam = c.camera(width=24, spp=16, depth=8)
+    whole, _ = oo.render(c, cam, seed=3)
+    parts = oo.render(c, cam, seed=3, s_begin=0, s_end=5)[0] + oo.render(c, cam, seed=3, s_begin=5, s_end=16)[0]
+    assert np.allclose(whole, parts, rtol=1e-13, atol=1e-15) and np.isfinite(whole).all()
+
+
+def test_resolve_bytes():
+    got = oo.resolve(np.array([0.0, 0.25 * 4, 1.0 * 4, 16.0 * 4, 1e-30, -1.0, float("nan")]), 4)
+    assert list(got) == [0, 128, 255, 255, 0, 0, 0]   # floor(256 * clamp(sqrt(mean), 0, 0.999))
+
+
+def test_png_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (13, 31, 3), dtype=np.uint8)
+    path = tmp_path / "x.png"
+    on.write_png(path, img)
+    assert np.array_equal(on.read_png(path), img)
+    # a file written by another encoder, with sub / up / average / paeth scanline filters
+    import struct
+    import zlib
+
+    def filtered(raw_rows, kind):
+        out, prev = bytearray(), bytes(len(raw_rows[0]))
+        for row in raw_rows:
+            cur = bytearray(row)
+            enc = bytearray(len(row))
+            for x in range(len(row)):
+                a = cur[x - 3] if x >= 3 else 0
+                b_ = prev[x]
+                c = prev[x - 3] if x >= 3 else 0
+                p = a + b_ - c
+                pa, pb, pc = abs(p - a), abs(p - b_), abs(p - c)
+                pred = [0, a, b_, (a + b_) // 2, a if pa <= pb and pa <= pc else (b_ if pb <= pc else c)][kind]
+                enc[x] = (cur[x] - pred) & 255
+            out += bytes([kind]) + enc
+            prev = bytes(cur)
+        return bytes(out)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+
+    for kind in range(5):
+        rows = [img[y].tobytes() for y in range(img.shape[0])]
+        data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 31, 13, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(filtered(rows, kind))) + chunk(b"IEND", b"")
+        path = tmp_path / f"f{kind}.png"
+        path.write_bytes(data)
+        assert np.array_equal(on.read_png(path), img), kind
+
+
+def test_every_scene_of_scenes_lisp_builds_and_renders_on_the_checker(tmp_path):
+    rng = np.random.default_rng(8)
+    earth = rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)
+    on.write_png(tmp_path / "earth.png", earth)
+    names = ["four-spheres", "bouncing-spheres", "chequered-spheres", "earth", "perlin-spheres", "quads", "simple-light", "cornell-box", "cornell-smoke", "final-scene"]
+    for name in names:
+        t = on.Tables(name, seed=5, image_path=tmp_path / "earth.png")
+        cam = t.camera(width=12, spp=4, depth=6)
+        sums, c = oo.render(t, cam, seed=2)
+        assert np.isfinite(sums).all() and sums.min() >= 0 and sums.max() > 0, name
+        assert c.rays >= c.paths
+    t = on.Tables("final-scene", seed=5, image_path=tmp_path / "earth.png")
+    kinds = t.objects()["kind"]
+    assert (kinds == on.ON_OBJ_QUAD).sum() == 400 * 6 + 2 and (kinds == on.ON_OBJ_SPHERE).sum() == 1000 + 7 and (kinds == on.ON_OBJ_MEDIUM).sum() == 2
+    with pytest.raises(on.OnnaError):
+        on.Tables("earth")   # needs an image
+    with pytest.raises(on.OnnaError):
+        on.Tables("no-such-scene")
