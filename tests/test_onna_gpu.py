@@ -132,8 +132,8 @@ def test_light_densities_match_the_checker():
     for d in (towards, stray):
         od = np.hstack([origin, d])
         got, exp = s.pdf_value(t.desc.lights, od), oo.pdf_value(t, t.desc.lights, od)
-        assert np.allclose(got, exp, rtol=1e-14, atol=0)
-    assert (oo.pdf_value(t, t.desc.lights, np.hstack([origin, towards])) > 0).mean() > 0.99
+        assert np.allclose(got, exp, rtol=1e-14, atol=0, equal_nan=True)   # (an origin inside the sphere: the square root of a negative number, on both sides)
+    assert (oo.pdf_value(t, t.desc.lights, np.hstack([origin, towards])) > 0).mean() > 0.97   # (origins inside the glass sphere give NaN)
     with pytest.raises(on.OnnaError):
         s.pdf_value(t.desc.world, np.hstack([origin, stray]))   # the world is not a list of spheres and quads
     s.close()
@@ -178,20 +178,18 @@ def test_sampling_the_lights_changes_the_noise_not_the_picture():
     t = on.Tables("cornell-box")
     cam = t.camera(width=32, spp=1024, depth=20)
     s = on.Scene(t)
-    with_lights, _ = s.render(cam, seed=1)
+    a1, a2 = s.render(cam, seed=1)[0] / 1024, s.render(cam, seed=2)[0] / 1024
     s.close()
     t.desc.lights = -1   # the material's own density alone
     s = on.Scene(t)
-    without, _ = s.render(cam, seed=1)
+    b1, b2 = s.render(cam, seed=1)[0] / 1024, s.render(cam, seed=2)[0] / 1024
     s.close()
-    a, b = with_lights / 1024, without / 1024
     # block means over 8x8 pixels: the same expectation, within what 65 536 samples a block allow
     blocks = lambda x: x.reshape(4, 8, 4, 8, 3).mean(axis=(1, 3))
-    assert np.allclose(blocks(a), blocks(b), rtol=0.12, atol=0.01)
-    assert abs(a.mean() - b.mean()) < 0.03 * b.mean()
-    # ... and far less noise with the lights sampled: that is what the list of lights is for
-    rough = lambda x: np.abs(np.diff(x, axis=1)).mean()
-    assert rough(a) < 0.6 * rough(b)
+    assert np.allclose(blocks(a1), blocks(b1), rtol=0.12, atol=0.01)
+    assert abs(a1.mean() - b1.mean()) < 0.03 * b1.mean()
+    # ... and less noise with the lights sampled (two seeds apart): that is what the list of lights is for
+    assert np.abs(a1 - a2).mean() < 0.6 * np.abs(b1 - b2).mean()
 
 
 def test_resolve_matches_the_checker_and_the_host_api():
