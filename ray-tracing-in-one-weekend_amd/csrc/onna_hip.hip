@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_batch(DScene sc, int32_t object,
     const LaneStack st = {stacks + threadIdx.x, kBlock};
     const Ray r = load_ray(rays + i);
     TapeDraw g = {uniforms ? uniforms + i * (size_t)k : nullptr, uniforms ? (int)k : 0, 0, false};
-    const Chain none = {{0, 0, 0, 0}, 0};
+    const Chain none = {0, 0, 0, 0, 0};
     Found f;
     on_hit h;
     memset(&h, 0, sizeof h);
@@ -82,13 +82,25 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uin
         const LaneStack st = {stacks + tid, kBlock};
         const uint32_t pixel = y * cam.image_width + x;
         double sum[3] = {0, 0, 0};
-        for (uint32_t s = s_begin; s < s_end; ++s) {
-            StreamDraw g;
-            g.g.init(seed, pixel, s);
-            const Ray r = get_ray(cam, (int)x, (int)y, (int)(s % cam.sqrt_spp), (int)(s / cam.sqrt_spp), g);
-            V c;
-            segments += ray_colour(sc, r, cam.max_depth, cam.background, st, g, c);
-            sum[0] += c.x; sum[1] += c.y; sum[2] += c.z;
+        // One loop over ray segments: a lane whose path has ended starts its pixel's next sample at once,
+        // whatever the other lanes of the wave are in the middle of.
+        uint32_t s = s_begin;
+        bool running = false;
+        StreamDraw g;
+        Path path;
+        while (running || s < s_end) {
+            if (!running) {
+                g.g.init(seed, pixel, s);
+                path_begin(path, get_ray(cam, (int)x, (int)y, (int)(s % cam.sqrt_spp), (int)(s / cam.sqrt_spp), g), cam.max_depth);
+                running = true;
+            }
+            if (path_segment(sc, path, cam.background, st, g)) {
+                ++segments;
+            } else {
+                sum[0] += path.out.x; sum[1] += path.out.y; sum[2] += path.out.z;
+                running = false;
+                ++s;
+            }
         }
         double *a = accum + 3 * (size_t)pixel;
         a[0] += sum[0]; a[1] += sum[1]; a[2] += sum[2];

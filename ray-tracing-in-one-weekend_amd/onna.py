@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _preload_hip_runtime, CSRC
 
-HIP_LIB = os.path.join(CSRC, "libonna_hip.so")
+HIP_LIB = os.environ.get("ONNA_HIP_LIB", os.path.join(CSRC, "libonna_hip.so"))   # override: A/B builds during tuning
 HOST_LIB = os.path.join(CSRC, "libonna_host.so")
 
 ON_OBJ_SPHERE, ON_OBJ_QUAD, ON_OBJ_LIST, ON_OBJ_BVH, ON_OBJ_TRANSLATE, ON_OBJ_ROTATE_Y, ON_OBJ_MEDIUM = range(7)
