@@ -362,6 +362,51 @@ def extra_configs(ranks, rt, main_world, rank, local_rank):
     for w, setup in worlds.values():
         if setup is not None:
             w.close()
+    if ranks.world == 1 and rank == 0:
+        out.extend(onna_configs(local_rank))
+    return out
+
+
+def onna_configs(device):
+    """The Lisp tracer's features (include/onna_hip.h): the Cornell box of onna/scenes.lisp:157-182 with
+    the camera of onna/onna.lisp:9-17 and the book's final scene (scenes.lisp:208-294), 100 stratified samples a pixel,
+    on_render into device memory timed by its own HIP events; beside the first the checker's rate on one host core
+    (oracle/onna_oracle.c on a 120x120 frame of the same scene and camera)."""
+    import tempfile
+    import torch
+    on = importlib.import_module("ray-tracing-in-one-weekend_amd.onna")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import onna_oracle_lib as oo   # (the checker: for the CPU figure beside the GPU's)
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        yy, xx = np.mgrid[0:256, 0:512]
+        on.write_png(os.path.join(tmp, "earth.png"), np.stack([(xx // 2) % 256, yy % 256, ((xx + yy) // 3) % 256], -1).astype(np.uint8))
+        for name, width in (("cornell-box", 600), ("final-scene", 400)):
+            t = on.Tables(name, seed=1, image_path=os.path.join(tmp, "earth.png"))
+            s = on.Scene(t, device)
+            cam = t.camera(width=width, spp=100, depth=50)
+            accum = torch.zeros(cam.image_height, cam.image_width, 3, dtype=torch.float64, device="cuda")
+            stream = torch.cuda.current_stream().cuda_stream
+            params = on.on_render_params(0, 100, 1)
+            s.render_device(cam, params, accum.data_ptr(), stream)   # warm-up
+            torch.cuda.synchronize()
+            ms = []
+            for _ in range(2):
+                st = on.rt_stats()
+                s.render_device(cam, params, accum.data_ptr(), stream, st)
+                ms.append(st.kernel_ms)
+            rec = {"config": f"onna {name}: {cam.image_width}x{cam.image_height}, 100 stratified samples, depth 50, f64 sums", "scene": name,
+                   "value": st.paths / np.mean(ms) / 1e3, "unit": "Mpaths/s", "kernel_ms_steps": ms, "rays_per_path": st.rays / st.paths,
+                   "mean_radiance": float(accum.mean().item()) / 300, "parity": "checker unpinned (no Lisp here); GPU == checker in tests/test_onna_gpu.py"}
+            if name == "cornell-box":
+                small = t.camera(width=120, spp=16, depth=50)
+                t0 = time.perf_counter()
+                _, c = oo.render(t, small, 1)
+                dt = time.perf_counter() - t0
+                rec["cpu_checker"] = {"value": c.paths / dt / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port", "sample": f"120x120 at 16 samples ({c.paths} paths, {dt:.1f} s)"}
+            out.append(rec)
+            del accum
+            s.close()
     return out
 
 
