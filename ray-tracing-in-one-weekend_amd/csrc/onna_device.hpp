@@ -61,8 +61,19 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kShadowAcne = (double)0.001f;    // camera.lisp:92, a single-float literal
 constexpr double kMediumStep = (double)0.0001f;   // scene.lisp:432
 
+// An object as the kernels read it: the description's fields with what a bvh visit needs -- kind, links, box -- in the
+// first 64 bytes, and a 256-byte stride, so that a node visit touches one cache line and a sphere two.
+struct __attribute__((aligned(64))) DObj {
+    uint32_t kind;
+    int32_t material, a, b;
+    double box[6];
+    double v[18];
+    double pad[6];
+};
+static_assert(sizeof(DObj) == 256, "DObj is four 64-byte lines");
+
 struct DScene {
-    const on_object_desc *objects;
+    const DObj *objects;
     const int32_t *children;      // list members, each list closed by -1 (on_scene_create adds the terminators)
     const on_material_desc *materials;
     const on_texture_desc *textures;
@@ -115,7 +126,7 @@ struct Chain {
 static_assert(kMaxChain == 4, "Chain holds four instances");
 
 // scene.lisp:329-330, 381-401
-__device__ __forceinline__ Ray enter_instance(const on_object_desc *o, const Ray &r) {
+__device__ __forceinline__ Ray enter_instance(const DObj *o, const Ray &r) {
     Ray q = r;
     if (o->kind == ON_OBJ_TRANSLATE) {
         q.o = padd1(r.o, neg(ld(o->v)));
@@ -148,7 +159,7 @@ __device__ __forceinline__ bool hit_aabb(const double *b, const Ray &r, double l
     return true;
 }
 // scene.lisp:165-179
-__device__ __forceinline__ bool sphere_time(const on_object_desc *o, const Ray &r, double lo, double hi, double &t_out) {
+__device__ __forceinline__ bool sphere_time(const DObj *o, const Ray &r, double lo, double hi, double &t_out) {
     const Ray centre = {ld(o->v), ld(o->v + 3), 0};
     const double radius = o->v[6];
     const V cur = at(centre, r.time);
@@ -166,7 +177,7 @@ __device__ __forceinline__ bool sphere_time(const on_object_desc *o, const Ray &
     return true;
 }
 // scene.lisp:240-262
-__device__ __forceinline__ bool quad_time(const on_object_desc *o, const Ray &r, double lo, double hi, double &t_out, double &alpha, double &beta) {
+__device__ __forceinline__ bool quad_time(const DObj *o, const Ray &r, double lo, double hi, double &t_out, double &alpha, double &beta) {
     const V normal = ld(o->v + 12);
     const double denom = dot(normal, r.d);
     if (fabs(denom) < 1e-8) return false;
@@ -214,7 +225,7 @@ __device__ __forceinline__ bool walk(const DScene &sc, int32_t root, const Ray &
             push(st, sp, kListTag | (pos + 1));
             code = member;
         }
-        const on_object_desc *o = sc.objects + code;
+        const DObj *o = sc.objects + code;
         const uint32_t kind = o->kind;
         if (kind == ON_OBJ_SPHERE) {
             double t;
@@ -254,7 +265,7 @@ __device__ __forceinline__ bool walk(const DScene &sc, int32_t root, const Ray &
 struct Hit { double t; V p, normal; double u, v; int32_t object, material; bool front; };
 __device__ __forceinline__ Hit hit_record(const DScene &sc, const Ray &world_ray, const Found &f) {
     const Ray r = under_chain(sc, world_ray, f.chain);
-    const on_object_desc *o = sc.objects + f.object;
+    const DObj *o = sc.objects + f.object;
     Hit h;
     h.t = f.t; h.object = f.object; h.material = o->material;
     h.p = at(r, f.t);
@@ -278,7 +289,7 @@ __device__ __forceinline__ Hit hit_record(const DScene &sc, const Ray &world_ray
     h.front = dot(r.d, outward) < 0;
     h.normal = h.front ? outward : neg(outward);
     for (int k = f.chain.n - 1; k >= 0; --k) {   // scene.lisp:332, 391-404, innermost first
-        const on_object_desc *op = sc.objects + f.chain.get(k);
+        const DObj *op = sc.objects + f.chain.get(k);
         if (op->kind == ON_OBJ_TRANSLATE) {
             h.p = padd1(h.p, ld(op->v));
         } else {
@@ -372,7 +383,7 @@ __device__ __forceinline__ ONB make_onb(V n) {
 __device__ __forceinline__ V onb_transform(const ONB &o, V v) { return add3(scaled(o.u, v.x), scaled(o.v, v.y), scaled(o.w, v.z)); }
 
 // object-pdf-value of one sphere or quad (scene.lisp:184-196, 267-283)
-__device__ __forceinline__ double one_pdf_value(const on_object_desc *o, V origin, V direction) {
+__device__ __forceinline__ double one_pdf_value(const DObj *o, V origin, V direction) {
     const Ray r = {origin, direction, 0};
     if (o->kind == ON_OBJ_SPHERE) {
         double t;
@@ -396,7 +407,7 @@ __device__ __forceinline__ double one_pdf_value(const on_object_desc *o, V origi
 }
 // ... of the lights: one of them, or a sequence (scene.lisp:106-111)
 __device__ __forceinline__ double object_pdf_value(const DScene &sc, int32_t obj, V origin, V direction) {
-    const on_object_desc *o = sc.objects + obj;
+    const DObj *o = sc.objects + obj;
     if (o->kind != ON_OBJ_LIST) return one_pdf_value(o, origin, direction);
     const double weight = 1.0 / (double)o->b;
     double sum = 0;
@@ -405,7 +416,7 @@ __device__ __forceinline__ double object_pdf_value(const DScene &sc, int32_t obj
 }
 // random-direction (scene.lisp:113-115, 198-211, 285-290)
 template <class G> __device__ __forceinline__ V object_random_direction(const DScene &sc, int32_t obj, V origin, G &g) {
-    const on_object_desc *o = sc.objects + obj;
+    const DObj *o = sc.objects + obj;
     if (o->kind == ON_OBJ_LIST) {
         int i = (int)floor(g.uniform() * o->b);
         if (i >= o->b) i = o->b - 1;

@@ -5,7 +5,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -67,28 +69,33 @@ __global__ __launch_bounds__(kBlock) void k_pdf_value_batch(DScene sc, int32_t o
     out[i] = object_pdf_value(sc, object, ld(od + 6 * i), ld(od + 6 * i + 3));
 }
 
-// render (camera.lisp:165-181): a lane per pixel, a wave per 8x8 pixels, a block per 16x16.  The lane
-// runs its pixel's samples one after the other and adds them in that order (blend-colours sums a
-// pixel's samples in the order they were collected: colour.lisp:20-29).
-__global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uint32_t s_begin, uint32_t s_end, uint64_t seed, double *accum,
-                                                  unsigned long long *counters) {
+// render (camera.lisp:165-181): a lane per pixel and chunk of its samples, a wave per 8x8 pixels, a block per 16x16.
+// A lane runs its samples one after the other and adds them in that order (blend-colours sums a pixel's samples in
+// the order they were collected: colour.lisp:20-29).  With one chunk the sum goes straight to the image; with
+// several -- frames too small to fill the GPU with one lane per pixel -- each chunk's sum goes to `partial`
+// ([chunk][pixel][3]) and k_combine adds a pixel's chunks in chunk order: the frame is the same whichever lane ran what.
+__global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uint32_t s_begin, uint32_t s_end, uint32_t chunks, uint64_t seed,
+                                                  double *accum, double *partial, unsigned long long *counters) {
     __shared__ int32_t stacks[kStackCap * kBlock];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t tiles_x = (cam.image_width + 15u) / 16u;
-    const uint32_t x = (blockIdx.x % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = (blockIdx.x / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t tiles_x = (cam.image_width + 15u) / 16u, tiles = tiles_x * ((cam.image_height + 15u) / 16u);
+    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const uint32_t x = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t y = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t spp = s_end - s_begin;
+    const uint32_t my_begin = s_begin + (uint32_t)((uint64_t)spp * chunk / chunks), my_end = s_begin + (uint32_t)((uint64_t)spp * (chunk + 1) / chunks);
     unsigned long long segments = 0;
     if (x < cam.image_width && y < cam.image_height) {
         const LaneStack st = {stacks + tid, kBlock};
         const uint32_t pixel = y * cam.image_width + x;
         double sum[3] = {0, 0, 0};
-        // One loop over ray segments: a lane whose path has ended starts its pixel's next sample at once,
-        // whatever the other lanes of the wave are in the middle of.
-        uint32_t s = s_begin;
+        // One loop over ray segments: a lane whose path has ended starts its next sample at once, whatever the
+        // other lanes of the wave are in the middle of.
+        uint32_t s = my_begin;
         bool running = false;
         StreamDraw g;
         Path path;
-        while (running || s < s_end) {
+        while (running || s < my_end) {
             if (!running) {
                 g.g.init(seed, pixel, s);
                 path_begin(path, get_ray(cam, (int)x, (int)y, (int)(s % cam.sqrt_spp), (int)(s / cam.sqrt_spp), g), cam.max_depth);
@@ -102,12 +109,26 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uin
                 ++s;
             }
         }
-        double *a = accum + 3 * (size_t)pixel;
-        a[0] += sum[0]; a[1] += sum[1]; a[2] += sum[2];
+        if (chunks == 1) {
+            double *a = accum + 3 * (size_t)pixel;
+            a[0] += sum[0]; a[1] += sum[1]; a[2] += sum[2];
+        } else {
+            double *a = partial + 3 * ((size_t)chunk * cam.image_width * cam.image_height + pixel);
+            a[0] = sum[0]; a[1] = sum[1]; a[2] = sum[2];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) segments += __shfl_xor(segments, off);
     if (lane == 0) atomicAdd(counters, segments);
+}
+
+// a pixel's chunk sums, added in chunk order, then to the image
+__global__ __launch_bounds__(kBlock) void k_combine(const double *partial, size_t n_values, uint32_t chunks, double *accum) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_values) return;
+    double sum = 0;
+    for (uint32_t c = 0; c < chunks; ++c) sum += partial[(size_t)c * n_values + i];
+    accum[i] += sum;
 }
 
 // blend-colours, gamma-2, colour-8bit (colour.lisp:12-37; image.lisp:30-40)
@@ -223,7 +244,7 @@ struct shape_check {
 struct on_scene {
     int device = 0;
     DScene d{};
-    dev_buf<on_object_desc> objects;
+    dev_buf<DObj> objects;
     dev_buf<int32_t> children;
     dev_buf<on_material_desc> materials;
     dev_buf<on_texture_desc> textures;
@@ -231,6 +252,9 @@ struct on_scene {
     dev_buf<uint8_t> pixels;
     dev_buf<on_perlin_desc> perlins;
     dev_buf<unsigned long long> counter;
+    dev_buf<double> partial;            // chunk sums of frames rendered in several chunks per pixel (see k_render)
+    size_t partial_capacity = 0;
+    int n_cus = 256;
     uint32_t n_objects = 0, n_textures = 0;
     std::vector<char> media_below, plain, walkable;   // per object
     bool renderable = false;
@@ -325,9 +349,17 @@ static int scene_create(const on_scene_desc *desc, int device, on_scene **out) {
     }
 
     // device tables; every list's members are followed by a terminator
-    std::vector<on_object_desc> objects(desc->objects, desc->objects + desc->n_objects);
+    std::vector<DObj> objects(desc->n_objects);
+    for (uint32_t i = 0; i < desc->n_objects; ++i) {
+        const on_object_desc &in = desc->objects[i];
+        DObj &o = objects[i];
+        memset(&o, 0, sizeof o);
+        o.kind = in.kind; o.material = in.material; o.a = in.a; o.b = in.b;
+        memcpy(o.box, in.box, sizeof o.box);
+        memcpy(o.v, in.v, sizeof o.v);
+    }
     std::vector<int32_t> children;
-    for (on_object_desc &o : objects)
+    for (DObj &o : objects)
         if (o.kind == ON_OBJ_LIST) {
             const int32_t first = (int32_t)children.size();
             children.insert(children.end(), desc->children + o.a, desc->children + o.a + o.b);
@@ -338,6 +370,10 @@ static int scene_create(const on_scene_desc *desc, int device, on_scene **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_E_DEVICE, "no HIP device available");
     if (int rc = use_device(device, &device)) return rc;
     s->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
+    }
     hipError_t e = s->objects.upload(objects.data(), objects.size());
     if (e == hipSuccess) e = s->children.upload(children.data(), children.size());
     if (e == hipSuccess) e = s->materials.upload(desc->materials, desc->n_materials);
@@ -442,8 +478,24 @@ int on_render(on_scene *scene, const on_camera *camera, const on_render_params *
         HIP_TRY(hipEventRecord(ev.a, stream));
     }
     const uint32_t tiles = ((camera->image_width + 15u) / 16u) * ((camera->image_height + 15u) / 16u);
-    hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kBlock), 0, stream, scene->d, *camera, params->sample_begin, params->sample_end, params->seed, accum_dev,
-                       scene->counter.p);
+    // One lane per pixel fills the GPU only when the image is large: a frame of fewer pixels cuts every pixel's
+    // samples into chunks (at least four samples each) until there are about 8192 lanes per CU.
+    const uint32_t spp = params->sample_end - params->sample_begin;
+    const size_t n_values = (size_t)camera->image_width * camera->image_height * 3;
+    uint32_t chunks = 1;
+    {
+        const uint64_t lanes = (uint64_t)tiles * kBlock, wanted = (uint64_t)scene->n_cus * 8192;
+        if (lanes < wanted && spp >= 8) chunks = (uint32_t)std::min<uint64_t>((wanted + lanes - 1) / lanes, spp / 4);
+        if (const char *e = getenv("ONNA_CHUNKS")) chunks = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::max(1u, spp)));   // (tests, A/B)
+    }
+    if (chunks > 1 && scene->partial_capacity < n_values * chunks) {   // (grown on demand; the allocation may synchronise the device)
+        if (scene->partial.p) { (void)hipFree(scene->partial.p); scene->partial.p = nullptr; scene->partial_capacity = 0; }
+        HIP_TRY(scene->partial.alloc(n_values * chunks));
+        scene->partial_capacity = n_values * chunks;
+    }
+    hipLaunchKernelGGL(k_render, dim3(tiles * chunks), dim3(kBlock), 0, stream, scene->d, *camera, params->sample_begin, params->sample_end, chunks, params->seed,
+                       accum_dev, scene->partial.p, scene->counter.p);
+    if (chunks > 1) hipLaunchKernelGGL(k_combine, dim3(grid_for(n_values)), dim3(kBlock), 0, stream, scene->partial.p, n_values, chunks, accum_dev);
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(ev.b, stream));
