@@ -398,12 +398,20 @@ def onna_configs(device):
             rec = {"config": f"onna {name}: {cam.image_width}x{cam.image_height}, 100 stratified samples, depth 50, f64 sums", "scene": name,
                    "value": st.paths / np.mean(ms) / 1e3, "unit": "Mpaths/s", "kernel_ms_steps": ms, "rays_per_path": st.rays / st.paths,
                    "mean_radiance": float(accum.mean().item()) / 300, "parity": "checker unpinned (no Lisp here); GPU == checker in tests/test_onna_gpu.py"}
-            if name == "cornell-box":
-                small = t.camera(width=120, spp=16, depth=50)
-                t0 = time.perf_counter()
-                _, c = oo.render(t, small, 1)
-                dt = time.perf_counter() - t0
-                rec["cpu_checker"] = {"value": c.paths / dt / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port", "sample": f"120x120 at 16 samples ({c.paths} paths, {dt:.1f} s)"}
+            # the checker on one host core over a small frame of the same scene and camera: the CPU figure, and the
+            # counts of the Lisp traversal (box, sphere and quad tests per ray) for the algorithmic flops per path
+            small = t.camera(width=120, spp=16, depth=50)
+            t0 = time.perf_counter()
+            _, c = oo.render(t, small, 1)
+            dt = time.perf_counter() - t0
+            rec["cpu_checker"] = {"value": c.paths / dt / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port", "sample": f"120x120 at 16 samples ({c.paths} paths, {dt:.1f} s)"}
+            per_ray = {"box_tests": c.box_tests / c.rays, "sphere_tests": c.sphere_tests / c.rays, "quad_tests": c.quad_tests / c.rays}
+            # a box test 27 flops and a sphere test 30 as for the C++ path; a quad test 39 (two dot products, a division,
+            # the point, two cross products and two more dot products: scene.lisp:240-255); 60 for shading a segment
+            flop_path = (c.rays / c.paths) * (per_ray["box_tests"] * 27 + per_ray["sphere_tests"] * 30 + per_ray["quad_tests"] * 39 + 60)
+            achieved = flop_path * st.paths / (np.mean(ms) * 1e-3) / 1e12
+            rec["roofline"] = {"bound": "valu", "what": "algorithmic flops of the Lisp traversal (counts from the checker) / kernel time against the f64 vector peak",
+                               "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6, "flop_per_path": flop_path, "per_ray": per_ray, "traffic": None}
             out.append(rec)
             del accum
             s.close()

@@ -125,7 +125,7 @@ int on_pdf_value_batch(on_scene *scene, int32_t object, const double *od, size_t
  * (a hipStream_t, or NULL).  Every sample draws from its own random stream keyed by (seed, pixel,
  * sample), and a pixel's samples are added in sample order -- for frames of few pixels in several
  * chunks, each summed in order and the chunk sums added in order; how many is a function of the
- * image size and the sample count alone -- so the frame does not depend on how the work was
+ * image size, the sample count and the GPU's size alone -- so the frame does not depend on how the work was
  * scheduled, and disjoint sample ranges add up to the whole frame's sums (a rounding per range
  * apart).  Such a frame's chunk sums live in a buffer of the scene's that is allocated on the first
  * call that needs it (that call may synchronise the device); renders of ONE scene must not overlap
