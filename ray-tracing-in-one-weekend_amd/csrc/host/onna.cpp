@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 
 namespace onna {
 
@@ -773,6 +774,41 @@ frame render(on_camera const& camera, device_scene const& scene, uint64_t seed) 
 frame render(on_camera const& camera, object_ptr const& world, object_ptr const& lights, uint64_t seed, int device) {
     device_scene const scene(world, lights, device);
     return render(camera, scene, seed);
+}
+
+frame render(on_camera const& camera, object_ptr const& world, object_ptr const& lights, uint64_t seed, std::vector<int> const& devices) {
+    if (devices.empty()) return render(camera, world, lights, seed, -1);
+    size_t const n = devices.size();
+    uint32_t const samples = camera.sqrt_spp * camera.sqrt_spp;
+    std::vector<frame> parts(n);
+    std::vector<std::string> errors(n);
+    auto share = [&](size_t g) {
+        try {
+            device_scene const scene(world, lights, devices[g]);
+            frame& f = parts[g];
+            f.width = camera.image_width; f.height = camera.image_height; f.samples = samples;
+            f.sums.assign((size_t)f.width * f.height * 3, 0.0);
+            on_render_params const p{(uint32_t)((uint64_t)samples * g / n), (uint32_t)((uint64_t)samples * (g + 1) / n), seed};
+            if (p.sample_end > p.sample_begin && on_render_host(scene.handle(), &camera, &p, f.sums.data(), &f.stats))
+                throw std::runtime_error(std::string("on_render_host: ") + on_last_error());
+        } catch (std::exception const& e) {
+            errors[g] = e.what();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t g = 1; g < n; ++g) threads.emplace_back(share, g);
+    share(0);
+    for (auto& t : threads) t.join();
+    for (size_t g = 0; g < n; ++g)
+        if (!errors[g].empty()) throw std::runtime_error("onna: render on device " + std::to_string(devices[g]) + ": " + errors[g]);
+    frame out = std::move(parts[0]);
+    for (size_t g = 1; g < n; ++g) {
+        for (size_t i = 0; i < out.sums.size(); ++i) out.sums[i] += parts[g].sums[i];
+        out.stats.rays += parts[g].stats.rays;
+        out.stats.kernel_ms = std::max(out.stats.kernel_ms, parts[g].stats.kernel_ms);
+    }
+    out.stats.paths = (uint64_t)out.width * out.height * samples;
+    return out;
 }
 
 // colour.lisp:12-18,20-37; image.lisp:30-40 (the same arithmetic as on_resolve; a frame's worth on the host)

@@ -159,6 +159,11 @@ struct frame {
 };
 frame render(on_camera const& camera, device_scene const& scene, uint64_t seed = 0);
 frame render(on_camera const& camera, object_ptr const& world, object_ptr const& lights, uint64_t seed = 0, int device = -1);
+// The same frame from several GPUs of the node (the reference's README.md:21-23 proposes the split for threads): GPU g
+// of the list renders the samples [g S / n, (g + 1) S / n) of every pixel on a host thread of its own, and the per-GPU
+// sums are added on the host in the order of the list.  The random streams are keyed by (pixel, sample): the paths are
+// the ones a single GPU traces.  A GPU may be listed more than once.
+frame render(on_camera const& camera, object_ptr const& world, object_ptr const& lights, uint64_t seed, std::vector<int> const& devices);
 
 // hit-test of one ray (scene.lisp:22): flattens `o`, uploads it and asks the GPU
 on_hit hit_test(rt_ray const& ray, object_ptr const& o, interval ray_interval, int device = -1);

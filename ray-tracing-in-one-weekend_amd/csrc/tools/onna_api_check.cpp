@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "onna.hpp"
 
@@ -46,6 +47,11 @@ int main() {
         write_png(path, img);
         image8 const back = read_png(path);
         CHECK(back.width == img.width && back.height == img.height && back.rgb == img.rgb);
+
+        // the frame's samples split over a list of GPUs (here the same one twice): the sums of the two ranges
+        frame const split = render(cam, s.world, s.lights, 7, std::vector<int>{0, 0});
+        CHECK(split.sums.size() == a.sums.size() && split.stats.paths == a.stats.paths && split.stats.rays == a.stats.rays);
+        for (size_t i = 0; i < a.sums.size(); ++i) CHECK(std::fabs(split.sums[i] - a.sums[i]) <= 1e-13 * std::fabs(a.sums[i]) + 1e-15);
 
         // errors are exceptions
         bool threw = false;

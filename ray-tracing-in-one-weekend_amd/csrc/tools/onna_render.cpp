@@ -7,6 +7,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "onna.hpp"
 
@@ -15,6 +16,7 @@ int main(int argc, char** argv) {
     uint32_t width = 0, samples = 0, depth = 0;
     uint64_t seed = 1;
     int device = -1;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         auto value = [&](char const* flag) -> char const* {
             if (std::strcmp(argv[i], flag) != 0) return nullptr;
@@ -29,8 +31,11 @@ int main(int argc, char** argv) {
         else if (char const* v = value("--depth")) depth = (uint32_t)std::atoi(v);
         else if (char const* v = value("--seed")) seed = std::strtoull(v, nullptr, 10);
         else if (char const* v = value("--device")) device = std::atoi(v);
+        else if (char const* v = value("--devices")) {   // 0,1,2,...: the frame's samples split over these GPUs
+            for (char const* q = v; *q;) { devices.push_back((int)std::strtol(q, const_cast<char**>(&q), 10)); if (*q == ',') ++q; }
+        }
         else {
-            std::fprintf(stderr, "usage: onna_render [--scene NAME] [--width W] [--samples N] [--depth D] [--seed S] [--device G] [--image earthmap.png] [--out FILE.png]\nscenes:");
+            std::fprintf(stderr, "usage: onna_render [--scene NAME] [--width W] [--samples N] [--depth D] [--seed S] [--device G | --devices 0,1,...] [--image earthmap.png] [--out FILE.png]\nscenes:");
             for (auto const& s : onna::scene_names()) std::fprintf(stderr, " %s", s.c_str());
             std::fprintf(stderr, "\n");
             return 2;
@@ -45,7 +50,7 @@ int main(int argc, char** argv) {
         if (samples) s.camera.samples_per_pixel = samples;
         if (depth) s.camera.max_depth = depth;
         on_camera const cam = onna::make_camera(s.camera);
-        onna::frame const f = onna::render(cam, s.world, s.lights, seed, device);
+        onna::frame const f = devices.empty() ? onna::render(cam, s.world, s.lights, seed, device) : onna::render(cam, s.world, s.lights, seed, devices);
         onna::write_png(out, f.resolve());
         std::fprintf(stderr, "Render duration: %.3f s (%ux%u, %u samples per pixel, %.1f Mpaths/s, %.2f rays per path)\n", f.stats.kernel_ms * 1e-3, f.width,
                      f.height, f.samples, (double)f.stats.paths / (f.stats.kernel_ms * 1e3), (double)f.stats.rays / (double)f.stats.paths);
