@@ -390,3 +390,33 @@ def test_every_scene_of_scenes_lisp_builds_and_renders_on_the_checker(tmp_path):
         on.Tables("earth")   # needs an image
     with pytest.raises(on.OnnaError):
         on.Tables("no-such-scene")
+
+
+def _split_worker(rank, world, port, out_path):
+    # one rank of a two-rank frame: its share of every pixel's strata (the checker standing in for the GPU kernel, which
+    # renders the same per-(pixel, sample) streams), then the sum of the f64 buffers over gloo as RCCL would do it
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = on.Tables("cornell-box")
+    cam = t.camera(width=20, spp=9, depth=8)
+    spp = cam.sqrt_spp * cam.sqrt_spp
+    sums, _ = oo.render(t, cam, seed=13, s_begin=spp * rank // world, s_end=spp * (rank + 1) // world)
+    accum = torch.from_numpy(sums)
+    dist.all_reduce(accum)
+    if rank == 0:
+        np.save(out_path, accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_split_a_frames_strata(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sum.npy")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_split_worker, args=(2, port, out), nprocs=2, join=True)
+    t = on.Tables("cornell-box")
+    whole, _ = oo.render(t, t.camera(width=20, spp=9, depth=8), seed=13)
+    np.testing.assert_allclose(np.load(out), whole, rtol=1e-13, atol=1e-15)
