@@ -368,7 +368,7 @@ def extra_configs(ranks, rt, main_world, rank, local_rank):
 
 
 def onna_configs(device):
-    """The Lisp tracer's features (include/onna_hip.h): the Cornell box of onna/scenes.lisp:157-182 with
+    """The features that only the reference's Lisp tracer has (include/onna_hip.h): the Cornell box of onna/scenes.lisp:157-182 with
     the camera of onna/onna.lisp:9-17 and the book's final scene (scenes.lisp:208-294), 100 stratified samples a pixel,
     on_render into device memory timed by its own HIP events; beside the first the checker's rate on one host core
     (oracle/onna_oracle.c on a 120x120 frame of the same scene and camera)."""
