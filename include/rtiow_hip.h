@@ -181,7 +181,7 @@ int rt_render_multi(rt_scene *const *scenes, uint32_t n_scenes, const rt_camera 
  * trees too large for LDS -- lies in a 32 MiB array that is part of the library's device
  * image (every GPU the library runs on holds it until the process ends), so the call makes
  * no hipMalloc / hipFree.  Limits, reported as RT_E_UNSUPPORTED: frames of 32 or more samples
- * per pixel (those whose tiles are ordered by cost) may have at most 2^19 tiles, counted in
+ * per pixel (those whose tiles are ordered by cost) may have at most 2^19 - 8 tiles, counted in
  * tiles of the size the frame is rendered in -- 4x4 pixels unless the RTIOW_TILE_SHIFT switch
  * says otherwise, i.e. about 8.3 M pixels: 3840x2160 fits -- and the scene's stack spill at
  * most 28 MiB less 256 bytes (what the array has left beside the counters and the 4 MiB of tile

@@ -188,10 +188,23 @@ constexpr size_t kCameraLds = 192;            // the block's copy of the camera
 constexpr size_t kHeadLds = kCameraLds + 64 + 16 * 16;  // ... followed by the scene's FarSlack and reach, 1/nx and 1/ny, and each wave's four open tiles
 constexpr int kSpillStackCap = 12;                      // LDS stack entries per lane when the tree is in device memory
 #ifdef RT_LANE_STATS
-constexpr size_t kCounters = 4 + 16 * 16 * 1024;        // + 16 statistics slots (12 lane counts, 3 phase clocks) per wave of up to 1024 blocks
+constexpr size_t kPassCounters = 12;                    // of one pass: [0] rays, [1] the tile queue, [4..11] a queue position per XCD
+constexpr size_t kQueueCounters = 2 * kPassCounters;    // the frame's, then the costing pass's
+constexpr size_t kCounters = kQueueCounters + 16 * 16 * 1024;        // + 16 statistics slots (12 lane counts, 3 phase clocks) per wave of up to 1024 blocks
 #else
-constexpr size_t kCounters = 4;                         // rays, tile queue, and the same for the costing pass
+constexpr size_t kPassCounters = 12;                    // of one pass: [0] rays, [1] the tile queue, [4..11] a queue position per XCD
+constexpr size_t kQueueCounters = 2 * kPassCounters;    // the frame's, then the costing pass's
+constexpr size_t kCounters = kQueueCounters;
 #endif
+// strip q of `regions` covers the tile columns [q tiles_x / regions, (q + 1) tiles_x / regions)
+__host__ __device__ inline uint32_t strip_begin(uint32_t q, uint32_t tiles_x, uint32_t regions) { return (uint32_t)((uint64_t)q * tiles_x / regions); }
+__host__ __device__ inline uint32_t strip_of(uint32_t x, uint32_t tiles_x, uint32_t regions) {
+    uint32_t q = (uint32_t)(((uint64_t)x * regions + regions - 1) / tiles_x);   // an estimate, then exact
+    if (q >= regions) q = regions - 1;
+    while (q > 0 && strip_begin(q, tiles_x, regions) > x) --q;
+    while (q + 1 < regions && strip_begin(q + 1, tiles_x, regions) <= x) ++q;
+    return q;
+}
 constexpr uint32_t kOrderMinSamples = 32;               // frames at least this deep get their tiles ordered by cost
 constexpr uint32_t kSamplesPerLaunch = 4096;            // samples a launch may add to a pixel's 64-bit sums (2^51 units each at most)
 
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                                                        AccT *accum, unsigned long long *counters, uint32_t n_lnodes,
                                                        uint32_t n_lleaves, uint32_t stack_cap, int *spill,
                                                        const uint32_t *tile_order, uint32_t *tile_cost, uint32_t tile_shift,
-                                                       uint32_t sums_per_wave) {
+                                                       uint32_t sums_per_wave, uint32_t regions) {
     constexpr int kRenderBlock = 256 * WAVES, kRenderWaves = 4 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
     unsigned long long nrays = 0;
     LaneStats lane_stats;
 #ifdef RT_LANE_STATS
-    if (!COSTING) lane_stats.c = counters + 4 + 16 * (blockIdx.x * 16 + wave);   // zeroed by rt_render
+    if (!COSTING) lane_stats.c = counters + kQueueCounters + 16 * (blockIdx.x * 16 + wave);   // zeroed by rt_render
 #endif
 
     // A wave keeps up to `ring` tiles open at a time: one whose paths it is still claiming, the others
@@ -349,8 +362,24 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
             if (ring_used != (1u << ring) - 1u) {
                 uint32_t tile = 0;
                 if (lane == 0) {
-                    tile = (uint32_t)atomicAdd(counters + 1, 1ull);
-                    if (tile < n_tiles && tile_order) tile = tile_order[tile];
+                    if (regions > 1) {
+                        // A tree in device memory: the frame is cut into vertical strips, one per XCD, each with its own
+                        // queue (dearest tile first), so that the nodes a strip's rays visit gather in that XCD's L2
+                        // instead of every L2 holding a thin slice of everything.  Blocks are dealt to the XCDs in turn
+                        // (block b runs on XCD b % 8); a block whose strip is used up helps with the next ones.
+                        const uint32_t *seg = tile_order + n_tiles;   // where each strip starts in the order, and n_tiles last
+                        tile = n_tiles;
+                        uint32_t q = blockIdx.x % regions;
+                        for (uint32_t tries = 0; tries < regions; ++tries, q = q + 1 == regions ? 0 : q + 1) {
+                            const uint32_t len = seg[q + 1] - seg[q];
+                            if (__hip_atomic_load(counters + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+                            const uint32_t pos = (uint32_t)atomicAdd(counters + 4 + q, 1ull);
+                            if (pos < len) { tile = tile_order[seg[q] + pos]; break; }
+                        }
+                    } else {
+                        tile = (uint32_t)atomicAdd(counters + 1, 1ull);
+                        if (tile < n_tiles && tile_order) tile = tile_order[tile];
+                    }
                 }
                 tile = __builtin_amdgcn_readfirstlane(tile);
                 if (tile >= n_tiles) {
@@ -480,13 +509,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float *accum, size_t n
 // wave); when the frame is rendered in smaller tiles each inherits the cost of the 8x8 tile
 // it lies in (`sub` = log2 of the ratio of the sides).
 constexpr int kOrderBlock = 1024;
+constexpr uint32_t kRegions = 8;   // vertical strips of a frame whose tree is in device memory: one per XCD (see k_render)
+// `regions` > 1: the tiles of each vertical strip of the frame are ordered on their own, strip after strip, and
+// order[n .. n + regions] receives where each strip starts (and, last, n).
 __global__ __launch_bounds__(kOrderBlock) void k_order_tiles(const uint32_t *cost, uint32_t cost_tiles_x, uint32_t n_cost,
-                                                            uint32_t tiles_x, uint32_t n, uint32_t sub, uint32_t *order) {
+                                                            uint32_t tiles_x, uint32_t n, uint32_t sub, uint32_t *order, uint32_t regions) {
     __shared__ uint32_t hist[kOrderBlock];
-    __shared__ uint32_t cmax;
+    __shared__ uint32_t cmax, base;
     const uint32_t tid = threadIdx.x;
-    hist[tid] = 0;
-    if (tid == 0) cmax = 1;
+    if (tid == 0) { cmax = 1; base = 0; }
     __syncthreads();
     uint32_t m = 1;
     for (uint32_t i = tid; i < n_cost; i += kOrderBlock) m = cost[i] > m ? cost[i] : m;
@@ -497,14 +528,27 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_tiles(const uint32_t *cos
         const uint32_t x = i % tiles_x, y = i / tiles_x;
         return (uint32_t)((unsigned long long)cost[(y >> sub) * cost_tiles_x + (x >> sub)] * (kOrderBlock - 1) / top);
     };
-    for (uint32_t i = tid; i < n; i += kOrderBlock) atomicAdd(&hist[klass(i)], 1u);
-    __syncthreads();
-    if (tid == 0) {   // start of each class in the output, dearest class first
-        uint32_t at = 0;
-        for (int b = kOrderBlock - 1; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = at; at += c; }
+    // (vertical strips: measured 45.1 ms on 10^6 spheres against 46.8 for horizontal bands, 46.4 / 46.9 for 4 x 2 / 2 x 4
+    // blocks and 47.9 for one queue; the order inside a strip -- dearest first or row by row -- makes no difference)
+    auto region = [&](uint32_t i) { return regions > 1 ? strip_of(i % tiles_x, tiles_x, regions) : 0u; };
+    for (uint32_t r = 0; r < (regions > 1 ? regions : 1u); ++r) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kOrderBlock)
+            if (region(i) == r) atomicAdd(&hist[klass(i)], 1u);
+        __syncthreads();
+        if (tid == 0) {   // start of each class in the output, dearest class first
+            uint32_t at = base;
+            if (regions > 1) order[n + r] = base;
+            for (int b = kOrderBlock - 1; b >= 0; --b) { const uint32_t c = hist[b]; hist[b] = at; at += c; }
+            base = at;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kOrderBlock)
+            if (region(i) == r) order[atomicAdd(&hist[klass(i)], 1u)] = i;
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += kOrderBlock) order[atomicAdd(&hist[klass(i)], 1u)] = i;
+    if (tid == 0 && regions > 1) order[n + regions] = n;
 }
 
 }  // namespace
@@ -561,7 +605,8 @@ int use_device(int device, int *chosen) {
 // process ends.  In host code the name `scratch` is a stand-in, not a device address: the address on
 // each device is asked for once (scratch_on_device) and only that pointer is handed to kernels and
 // to hipMemsetAsync.
-constexpr size_t kScratchCounterBytes = 256;                   // the four frame counters
+constexpr size_t kScratchCounterBytes = 256;                   // the frame counters (kQueueCounters of them)
+static_assert(kQueueCounters * sizeof(unsigned long long) <= kScratchCounterBytes, "the frame counters fit their part of the scratch");
 constexpr size_t kScratchTiles = (size_t)1 << 20;              // tile costs + tile order: at most 2^20 entries together
 constexpr size_t kScratchBytes = (size_t)32 << 20;             // in all
 constexpr size_t kScratchSpillInts = (kScratchBytes - kScratchCounterBytes - kScratchTiles * sizeof(uint32_t)) / sizeof(int);
@@ -1770,6 +1815,7 @@ static int check_render_args(const char *who, rt_scene *scene, const rt_camera *
 struct frame_plan {
     uint32_t tile_shift, tiles_x, n_tiles, waves, blocks;
     bool ordered;
+    uint32_t regions;   // > 1: a strip of the frame and a tile queue per XCD
 };
 
 static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) {
@@ -1790,6 +1836,11 @@ static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) 
     // Worth a costing pass when every wave gets several tiles and the frame is many samples deep:
     // the pass traces 1 to 4 samples per pixel without touching the image, under 2 % of the work.
     f.ordered = spp >= kOrderMinSamples && f.n_tiles >= 2 * f.blocks * f.waves && !getenv("RTIOW_TILE_ORDER_OFF");
+    // a tree in device memory: the tiles of each of eight vertical strips go to the blocks of one XCD first
+    // (cost-ordered frames only: with the tiles handed out in image order -- frames under kOrderMinSamples samples, the costing
+    // pass -- strips measured slower, 8.3 against 7.2 ms for 8 samples of 10^6 spheres, and no different for the costing pass)
+    f.regions = f.ordered && !scene->render_lds_tree && f.tiles_x >= 4 * kRegions && f.blocks >= kRegions ? kRegions : 1u;
+    if (const char *e = getenv("RTIOW_TILE_REGIONS")) f.regions = f.ordered && atoi(e) > 1 && f.tiles_x >= kRegions ? kRegions : 1u;   // (A/B, tests)
     return f;
 }
 
@@ -1798,7 +1849,7 @@ static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) 
 static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_render_params *pr, void *accum_dev, hipStream_t stream,
                         const frame_plan &f, const frame_memory &mem, bool order_on_file) {
     const uint32_t spp = pr->sample_end - pr->sample_begin;
-    // counters[0] = rays traced, counters[1] = next tile of the frame; [2], [3]: the same for the costing pass
+    // counters[0] = rays traced, [1] = next tile of the frame, [4..11] = next tile of each XCD's strip; from kPassCounters on: the same for the costing pass
     HIP_TRY(hipMemsetAsync(mem.counters, 0, kCounters * sizeof(unsigned long long), stream));
     dim3 grid(f.blocks), block(64 * f.waves);
     DCamera cam = to_dcamera(camera);
@@ -1814,7 +1865,7 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     hipLaunchKernelGGL((k_render<T, L, W, C, D, X>), grid, block, scene->render_lds_bytes, stream, dsc, cam, pr->nx, pr->ny,   \
                        s_from, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                           \
                        scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT, \
-                       scene->render_sums_per_wave)
+                       scene->render_sums_per_wave, (ORDER) ? regions : 1u)
 #define RT_LAUNCH_TREE(T, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                      \
     do {                                                                                                                  \
         if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \
@@ -1832,14 +1883,16 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     } while (0)
     uint32_t s_from = pr->sample_begin;
     const uint32_t *order = nullptr;
+    // trees in device memory: a strip of the frame and a tile queue per XCD (see k_render)
+    const uint32_t regions = f.regions;
     if (f.ordered) {
         const uint32_t cost_tiles_x = (pr->nx + 7) / 8, n_cost = cost_tiles_x * ((pr->ny + 7) / 8);
         uint32_t *cost = mem.tiles, *sorted = mem.tiles + n_cost;
         uint32_t probe = std::min(4u, std::max(1u, spp / 64u));   // measured: 1 sample ranks noisily, more than 4 costs more than it saves
         if (const char *e = getenv("RTIOW_TILE_PROBE")) probe = std::min<uint32_t>(spp, (uint32_t)std::max(1, atoi(e)));
         if (!order_on_file) {
-            RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, mem.counters + 2, (const uint32_t *)nullptr, cost, 3u);
-            hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, f.tiles_x, f.n_tiles, 3u - f.tile_shift, sorted);
+            RT_LAUNCH_SHAPE(float, true, pr->sample_begin + probe, nullptr, mem.counters + kPassCounters, (const uint32_t *)nullptr, cost, 3u);
+            hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(kOrderBlock), 0, stream, cost, cost_tiles_x, n_cost, f.tiles_x, f.n_tiles, 3u - f.tile_shift, sorted, regions);
         }
         order = sorted;
     }
@@ -1847,7 +1900,7 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     for (uint64_t from = pr->sample_begin; from < pr->sample_end; from += kSamplesPerLaunch) {
         s_from = (uint32_t)from;
         const uint32_t s_to = pr->sample_end - s_from > kSamplesPerLaunch ? s_from + kSamplesPerLaunch : pr->sample_end;
-        if (s_from != pr->sample_begin) HIP_TRY(hipMemsetAsync(mem.counters + 1, 0, sizeof(unsigned long long), stream));   // the tile queue starts over
+        if (s_from != pr->sample_begin) HIP_TRY(hipMemsetAsync(mem.counters + 1, 0, (kPassCounters - 1) * sizeof(unsigned long long), stream));   // the tile queues start over
         if (pr->accum_type == RT_ACCUM_F32) RT_LAUNCH_SHAPE(float, false, s_to, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
         else RT_LAUNCH_SHAPE(double, false, s_to, accum_dev, mem.counters, order, (uint32_t *)nullptr, f.tile_shift);
     }
@@ -1869,11 +1922,11 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         ~event_pair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
     } ev;
     const frame_plan f = plan_frame(scene, pr);
-    if (f.ordered && scene->tiles_capacity < 2 * (size_t)f.n_tiles) {   // costs of the 8x8 tiles (at most n_tiles of them), then the order
+    if (f.ordered && scene->tiles_capacity < 2 * (size_t)f.n_tiles + 16) {   // costs of the 8x8 tiles (at most n_tiles of them), then the order and its strips' starts
         if (scene->tiles.p) { (void)hipFree(scene->tiles.p); scene->tiles.p = nullptr; scene->tiles_capacity = 0; }
         scene->order_valid = false;
-        HIP_TRY(scene->tiles.alloc(2 * (size_t)f.n_tiles));
-        scene->tiles_capacity = 2 * (size_t)f.n_tiles;
+        HIP_TRY(scene->tiles.alloc(2 * (size_t)f.n_tiles + 16));
+        scene->tiles_capacity = 2 * (size_t)f.n_tiles + 16;
     }
     if (stats) {
         HIP_TRY(hipEventCreate(&ev.a));
@@ -1887,7 +1940,7 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
     bool order_on_file = false;
     if (f.ordered) {
         rt_scene::order_key key{};
-        key.camera = *camera; key.nx = pr->nx; key.ny = pr->ny; key.max_depth = pr->max_depth; key.tile_shift = f.tile_shift; key.t_min = pr->t_min; key.stream = stream_v;
+        key.camera = *camera; key.nx = pr->nx; key.ny = pr->ny; key.max_depth = pr->max_depth; key.tile_shift = f.tile_shift | (f.regions << 8); key.t_min = pr->t_min; key.stream = stream_v;
         const char *reuse = getenv("RTIOW_TILE_COST_REUSE");
         order_on_file = scene->order_valid && memcmp(&key, &scene->order_of, sizeof key) == 0 && !(reuse && atoi(reuse) == 0) && !getenv("RTIOW_TILE_PROBE");
         scene->order_of = key;
@@ -1907,9 +1960,9 @@ int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_params *
         HIP_TRY(hipMemcpy(all.data(), scene->counter.p, kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long c[16] = {0};
         unsigned long long clk[3] = {0, 0, 0};
-        for (size_t w = 0; w < (kCounters - 4) / 16; ++w) {
-            for (int q = 0; q < 12; ++q) c[4 + q] += all[4 + 16 * w + q];
-            for (int q = 0; q < 3; ++q) clk[q] += all[4 + 16 * w + 12 + q];
+        for (size_t w = 0; w < (kCounters - kQueueCounters) / 16; ++w) {
+            for (int q = 0; q < 12; ++q) c[4 + q] += all[kQueueCounters + 16 * w + q];
+            for (int q = 0; q < 3; ++q) clk[q] += all[kQueueCounters + 16 * w + 12 + q];
         }
         {
             const double sum = (double)(clk[0] + clk[1] + clk[2]);
@@ -1936,9 +1989,9 @@ int rt_render_noalloc(rt_scene *scene, const rt_camera *camera, const rt_render_
     unsigned char *base = nullptr;
     if (int rc = scratch_on_device(scene->device, &base)) return rc;   // (looked up when the device's first scene was created)
     const frame_plan f = plan_frame(scene, pr);
-    if (f.ordered && 2 * (size_t)f.n_tiles > kScratchTiles)
+    if (f.ordered && 2 * (size_t)f.n_tiles + 16 > kScratchTiles)
         return fail(RT_E_UNSUPPORTED, "rt_render_noalloc: %u tiles of %ux%u pixels; the scratch area orders at most %zu (images up to about %zu pixels)",
-                    f.n_tiles, 1u << f.tile_shift, 1u << f.tile_shift, kScratchTiles / 2, kScratchTiles / 2 * 16);
+                    f.n_tiles, 1u << f.tile_shift, 1u << f.tile_shift, kScratchTiles / 2 - 8, (kScratchTiles / 2 - 8) * 16);
     if (scene->spill_ints > kScratchSpillInts)
         return fail(RT_E_UNSUPPORTED, "rt_render_noalloc: the scene's tree needs %zu bytes of stack spill, the scratch area holds %zu",
                     scene->spill_ints * sizeof(int), kScratchSpillInts * sizeof(int));

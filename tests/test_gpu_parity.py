@@ -754,6 +754,14 @@ def test_cost_ordered_tiles_render_the_same_frame(rt, worlds, monkeypatch):
         assert s_ordered.rays == s_plain.rays and s_ordered.paths == s_plain.paths == 800 * 640 * 32
         assert np.array_equal(ordered, plain)
         assert ordered.any()
+        # ... nor must a strip of the frame and a tile queue per XCD (the default for trees in device memory; forced here)
+        monkeypatch.setenv("RTIOW_TILE_REGIONS", "8")
+        strips, s_strips = w.render(rt.camera(cam15), 800, 640, 3, 3 + 32, 9, accum)
+        monkeypatch.setenv("RTIOW_TILE_REGIONS", "1")
+        single, s_single = w.render(rt.camera(cam15), 800, 640, 3, 3 + 32, 9, accum)
+        monkeypatch.delenv("RTIOW_TILE_REGIONS")
+        assert s_strips.rays == s_single.rays and s_strips.paths == 800 * 640 * 32
+        assert np.array_equal(strips, single) and strips.any() and not np.array_equal(strips, ordered)
 
 
 EDGE_FRAMES = [

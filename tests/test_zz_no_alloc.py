@@ -79,7 +79,7 @@ def test_noalloc_reports_its_limits(rt):
     w = rt.World(recipe("book1"))
     try:
         cam = rt.camera(golden("frames")["camera"])
-        # 2^19 ordered tiles of 4x4 pixels at most: 4096 x 2064 is 528 384 tiles
+        # 2^19 - 8 ordered tiles of 4x4 pixels at most: 4096 x 2064 is 528 384 tiles
         params = w.params(4096, 2064, 0, 32, seed=1, accum=rt.RT_ACCUM_F32)
         # (a buffer of the frame's full size: if the limit ever moves, the call renders instead of refusing)
         accum = torch.zeros(2064, 4096, 3, dtype=torch.float32, device="cuda")
