@@ -68,8 +68,11 @@ struct __attribute__((aligned(64))) DObj {
     int32_t material, a, b;
     double box[6];
     double v[18];
-    double pad[6];
+    uint32_t flags;      // kObjUsesUV
+    uint32_t pad0;
+    double pad[5];
 };
+constexpr uint32_t kObjUsesUV = 1u;   // a sphere whose material's texture reads (u, v): an image somewhere in it
 static_assert(sizeof(DObj) == 256, "DObj is four 64-byte lines");
 
 struct DScene {
@@ -263,7 +266,8 @@ __device__ __forceinline__ bool walk(const DScene &sc, int32_t root, const Ray &
 
 // the hit-record of the winner (scene.lisp:5-20, 151-164, 256-262, 446-452), carried out through its instances
 struct Hit { double t; V p, normal; double u, v; int32_t object, material; bool front; };
-__device__ __forceinline__ Hit hit_record(const DScene &sc, const Ray &world_ray, const Found &f) {
+// `every_uv` = false: a sphere's (u, v) -- an arc cosine and an arc tangent -- are left at zero where no texture reads them
+__device__ __forceinline__ Hit hit_record(const DScene &sc, const Ray &world_ray, const Found &f, bool every_uv = true) {
     const Ray r = under_chain(sc, world_ray, f.chain);
     const DObj *o = sc.objects + f.object;
     Hit h;
@@ -273,9 +277,12 @@ __device__ __forceinline__ Hit hit_record(const DScene &sc, const Ray &world_ray
     if (o->kind == ON_OBJ_SPHERE) {
         const Ray centre = {ld(o->v), ld(o->v + 3), 0};
         outward = scaled(sub(h.p, at(centre, r.time)), 1.0 / o->v[6]);
-        const double theta = acos(-outward.y), phi = atan2(-outward.z, outward.x) + kPi;
-        h.u = phi / (2 * kPi);
-        h.v = theta / kPi;
+        h.u = 0; h.v = 0;
+        if (every_uv || (o->flags & kObjUsesUV)) {   // scene.lisp:118-127
+            const double theta = acos(-outward.y), phi = atan2(-outward.z, outward.x) + kPi;
+            h.u = phi / (2 * kPi);
+            h.v = theta / kPi;
+        }
     } else if (o->kind == ON_OBJ_QUAD) {
         outward = ld(o->v + 12);
         const V planar = sub(h.p, ld(o->v));
@@ -492,13 +499,28 @@ __device__ __forceinline__ bool path_segment(const DScene &sc, Path &p, const do
     const Chain none = {0, 0, 0, 0, 0};
     const Ray r = p.r;
     V &thr = p.thr, &out = p.out;
+    // A world that is a sequence (scene.lisp:92-99) is taken member by member by all lanes together, each member with
+    // what the members before it left of the interval -- the order of the Lisp's loop -- so that the lanes enter
+    // every member's walk at the same time and in the same kind of object, instead of drifting apart down the list.
     Found f;
-    if (!walk<true>(sc, sc.world, r, none, kShadowAcne, HUGE_VAL, st, 0, g, f)) {
+    bool found = false;
+    {
+        const DObj *w = sc.objects + sc.world;
+        const bool sequence = w->kind == ON_OBJ_LIST;
+        double hi = HUGE_VAL;
+        for (int32_t pos = w->a;; ++pos) {
+            const int32_t member = sequence ? __builtin_amdgcn_readfirstlane(sc.children[pos]) : sc.world;
+            if (member < 0) break;
+            if (walk<true>(sc, member, r, none, kShadowAcne, hi, st, 0, g, f)) { found = true; hi = f.t; }   // (a walk writes `f` only for a hit before `hi`)
+            if (!sequence) break;
+        }
+    }
+    if (!found) {
         out = v3(out.x + thr.x * background[0], out.y + thr.y * background[1], out.z + thr.z * background[2]);
         p.depth = 0;
         return true;
     }
-    const Hit h = hit_record(sc, r, f);
+    const Hit h = hit_record(sc, r, f, false);
     const on_material_desc *m = sc.materials + h.material;
     const uint32_t kind = m->kind;
     if (kind == ON_MAT_DIFFUSE_LIGHT) {   // material.lisp:113-124: emits on its front face, scatters nothing

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(kBlock) void k_pdf_value_batch(DScene sc, int32_t o
 // the order they were collected: colour.lisp:20-29).  With one chunk the sum goes straight to the image; with
 // several -- frames too small to fill the GPU with one lane per pixel -- each chunk's sum goes to `partial`
 // ([chunk][pixel][3]) and k_combine adds a pixel's chunks in chunk order: the frame is the same whichever lane ran what.
+// (165 vector registers: three waves per SIMD.  The walk waits on its own loads, so occupancy is what its speed hangs on:
+// changes that push the count past 168 -- two waves -- have cost 20-30 % whatever else they did.)
 __global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uint32_t s_begin, uint32_t s_end, uint32_t chunks, uint64_t seed,
                                                   double *accum, double *partial, unsigned long long *counters) {
     __shared__ int32_t stacks[kStackCap * kBlock];
@@ -348,6 +350,17 @@ static int scene_create(const on_scene_desc *desc, int device, on_scene **out) {
         }
     }
 
+    // which materials' textures read a hit's (u, v): those with an image somewhere in them (a chequer's come before it)
+    std::vector<char> texture_reads_uv(desc->n_textures, 0), material_reads_uv(desc->n_materials, 0);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const on_texture_desc &t = desc->textures[i];
+        texture_reads_uv[i] = t.kind == ON_TEX_IMAGE || (t.kind == ON_TEX_CHEQUER && (texture_reads_uv[t.even] || texture_reads_uv[t.odd]));
+    }
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const on_material_desc &m = desc->materials[i];
+        const bool textured = m.kind == ON_MAT_LAMBERTIAN || m.kind == ON_MAT_DIFFUSE_LIGHT || m.kind == ON_MAT_ISOTROPIC;
+        material_reads_uv[i] = textured && texture_reads_uv[m.texture];
+    }
     // device tables; every list's members are followed by a terminator
     std::vector<DObj> objects(desc->n_objects);
     for (uint32_t i = 0; i < desc->n_objects; ++i) {
@@ -357,6 +370,7 @@ static int scene_create(const on_scene_desc *desc, int device, on_scene **out) {
         o.kind = in.kind; o.material = in.material; o.a = in.a; o.b = in.b;
         memcpy(o.box, in.box, sizeof o.box);
         memcpy(o.v, in.v, sizeof o.v);
+        if (in.kind == ON_OBJ_SPHERE && in.material >= 0 && material_reads_uv[in.material]) o.flags |= kObjUsesUV;
     }
     std::vector<int32_t> children;
     for (DObj &o : objects)
