@@ -23,4 +23,6 @@ run wide RTIOW_WIDE=1
 run wide_device_memory RTIOW_WIDE=1 RTIOW_RENDER_LDS_NODES=0 RTIOW_WIDE_STACK_CAP=4
 run device_build RTIOW_BUILD=device
 run device_build_unstaged RTIOW_BUILD=device RTIOW_RENDER_LDS_NODES=0 RTIOW_RENDER_STACK_CAP=2
+run strips RTIOW_TILE_REGIONS=8
+run strips_large_tree_shape RTIOW_TILE_REGIONS=8 RTIOW_RENDER_LDS_NODES=25 RTIOW_RENDER_STACK_CAP=2
 cat $OUT
