@@ -123,12 +123,13 @@ int on_pdf_value_batch(on_scene *scene, int32_t object, const double *od, size_t
  * [sample_begin, sample_end) of every pixel to accum_dev (device memory on the scene's GPU,
  * image_height * image_width * 3 doubles, row-major, top row first), asynchronously on `stream`
  * (a hipStream_t, or NULL).  Every sample draws from its own random stream keyed by (seed, pixel,
- * sample), and a pixel's samples are added in sample order -- for frames of few pixels in several
- * chunks, each summed in order and the chunk sums added in order; how many is a function of the
- * image size, the sample count and the GPU's size alone -- so the frame does not depend on how the work was
+ * sample) and leaves its colour in a slot of its own; a pixel's slots are then added in sample
+ * order and that sum is added to accum_dev -- so the frame does not depend on how the work was
  * scheduled, and disjoint sample ranges add up to the whole frame's sums (a rounding per range
- * apart).  Such a frame's chunk sums live in a buffer of the scene's that is allocated on the first
- * call that needs it (that call may synchronise the device); renders of ONE scene must not overlap
+ * apart).  The slots live in a buffer of the scene's (image_height * image_width * 3 doubles per
+ * sample, at most 1 GiB; allocated or grown by the first call that needs it, which may synchronise
+ * the device); calls with more samples than it holds go through in several passes, each pass's
+ * sum added to accum_dev in turn.  Renders of ONE scene must not overlap
  * in time.  stats may be NULL; when given, the call waits for the frame and fills it. */
 int on_render(on_scene *scene, const on_camera *camera, const on_render_params *params, double *accum_dev,
               void *stream, rt_stats *stats);

@@ -23,6 +23,8 @@ using namespace ond;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kShortestRun = 4, kRunShare = 35;   // k_render's runs of samples: each 35 % of what is left, at least 4
+constexpr size_t kSlotBudgetBytes = (size_t)1 << 30;   // of a scene's buffer of per-sample colours (see k_render)
 
 __device__ __forceinline__ Ray load_ray(const rt_ray *r) {
     Ray o;
@@ -69,54 +71,65 @@ __global__ __launch_bounds__(kBlock) void k_pdf_value_batch(DScene sc, int32_t o
     out[i] = object_pdf_value(sc, object, ld(od + 6 * i), ld(od + 6 * i + 3));
 }
 
-// render (camera.lisp:165-181): a lane per pixel and chunk of its samples, a wave per 8x8 pixels, a block per 16x16.
-// A lane runs its samples one after the other and adds them in that order (blend-colours sums a pixel's samples in
-// the order they were collected: colour.lisp:20-29).  With one chunk the sum goes straight to the image; with
-// several -- frames too small to fill the GPU with one lane per pixel -- each chunk's sum goes to `partial`
-// ([chunk][pixel][3]) and k_combine adds a pixel's chunks in chunk order: the frame is the same whichever lane ran what.
-// (165 vector registers: three waves per SIMD.  The walk waits on its own loads, so occupancy is what its speed hangs on:
+constexpr uint32_t kMaxRuns = 30;
+// render (camera.lisp:165-181).  A wave (a block) owns 8x8 pixels and a run of samples [s0, s1) of them, 64 (s1 - s0) paths in
+// all, numbered pixel-fastest (path k is pixel k % 64, sample s0 + k / 64).  One loop over ray segments: a lane whose path has
+// ended takes the next unstarted path of the wave at once -- one ballot and a count of the lanes below -- whatever the other
+// lanes are in the middle of, so no lane waits for a neighbour whose pixel is dearer than its own; what is left to wait for
+// at the wave's end is one path.  A path's colour goes to its own slot, slots[sample - w_begin][pixel][3], and k_combine adds
+// a pixel's slots in sample order (blend-colours sums a pixel's samples in the order they were collected: colour.lisp:20-29):
+// which lane traced what, and when, is not in the result.
+// (163 vector registers: three waves per SIMD.  The walk waits on its own loads, so occupancy is what its speed hangs on:
 // changes that push the count past 168 -- two waves -- have cost 20-30 % whatever else they did.)
-__global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uint32_t s_begin, uint32_t s_end, uint32_t chunks, uint64_t seed,
-                                                  double *accum, double *partial, unsigned long long *counters) {
-    __shared__ int32_t stacks[kStackCap * kBlock];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t tiles_x = (cam.image_width + 15u) / 16u, tiles = tiles_x * ((cam.image_height + 15u) / 16u);
-    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
-    const uint32_t x = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const uint32_t spp = s_end - s_begin;
-    const uint32_t my_begin = s_begin + (uint32_t)((uint64_t)spp * chunk / chunks), my_end = s_begin + (uint32_t)((uint64_t)spp * (chunk + 1) / chunks);
+struct SampleRuns { uint32_t n; uint32_t start[kMaxRuns + 1]; };   // run r of a window is its samples [start[r], start[r + 1])
+__global__ __launch_bounds__(64) void k_render(DScene sc, on_camera cam, uint32_t w_begin, SampleRuns runs, uint64_t seed,
+                                                      double *slots, unsigned long long *counters) {
+    __shared__ int32_t stacks[kStackCap * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles_x = (cam.image_width + 7u) / 8u, tiles = tiles_x * ((cam.image_height + 7u) / 8u);
+    const uint32_t tile = blockIdx.x % tiles, part = blockIdx.x / tiles;
+    const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
+    const uint32_t s0 = w_begin + runs.start[part], s1 = w_begin + runs.start[part + 1];
+    const uint32_t n_paths = 64u * (s1 - s0);
+    const size_t n_values = (size_t)cam.image_width * cam.image_height * 3;
+    const LaneStack st = {stacks + lane, 64};
     unsigned long long segments = 0;
-    if (x < cam.image_width && y < cam.image_height) {
-        const LaneStack st = {stacks + tid, kBlock};
-        const uint32_t pixel = y * cam.image_width + x;
-        double sum[3] = {0, 0, 0};
-        // One loop over ray segments: a lane whose path has ended starts its next sample at once, whatever the
-        // other lanes of the wave are in the middle of.
-        uint32_t s = my_begin;
-        bool running = false;
-        StreamDraw g;
-        Path path;
-        while (running || s < my_end) {
-            if (!running) {
-                g.g.init(seed, pixel, s);
-                path_begin(path, get_ray(cam, (int)x, (int)y, (int)(s % cam.sqrt_spp), (int)(s / cam.sqrt_spp), g), cam.max_depth);
-                running = true;
+    uint32_t next = 0;   // the same in every lane
+    uint32_t pixel = 0, sample = 0;
+    bool running = false, done = false;
+    StreamDraw g;
+    Path path;
+    for (;;) {
+        for (;;) {   // free lanes take paths; a path of a pixel beyond the image's edge is dropped and the lane asks again
+            const bool want = !running && !done;
+            const unsigned long long need = __ballot(want);
+            if (need == 0) break;
+            if (want) {
+                const uint32_t k = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                if (k >= n_paths) {
+                    done = true;
+                } else {
+                    const uint32_t x = x0 + (k & 7u), y = y0 + ((k >> 3) & 7u);
+                    if (x < cam.image_width && y < cam.image_height) {
+                        pixel = y * cam.image_width + x;
+                        sample = s0 + (k >> 6);
+                        g.g.init(seed, pixel, sample);
+                        path_begin(path, get_ray(cam, (int)x, (int)y, (int)(sample % cam.sqrt_spp), (int)(sample / cam.sqrt_spp), g), cam.max_depth);
+                        running = true;
+                    }
+                }
             }
+            next += (uint32_t)__popcll(need);
+        }
+        if (__ballot(running) == 0) break;
+        if (running) {
             if (path_segment(sc, path, cam.background, st, g)) {
                 ++segments;
             } else {
-                sum[0] += path.out.x; sum[1] += path.out.y; sum[2] += path.out.z;
+                double *o = slots + (size_t)(sample - w_begin) * n_values + 3 * (size_t)pixel;
+                o[0] = path.out.x; o[1] = path.out.y; o[2] = path.out.z;
                 running = false;
-                ++s;
             }
-        }
-        if (chunks == 1) {
-            double *a = accum + 3 * (size_t)pixel;
-            a[0] += sum[0]; a[1] += sum[1]; a[2] += sum[2];
-        } else {
-            double *a = partial + 3 * ((size_t)chunk * cam.image_width * cam.image_height + pixel);
-            a[0] = sum[0]; a[1] = sum[1]; a[2] = sum[2];
         }
     }
 #pragma unroll
@@ -124,12 +137,12 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, on_camera cam, uin
     if (lane == 0) atomicAdd(counters, segments);
 }
 
-// a pixel's chunk sums, added in chunk order, then to the image
-__global__ __launch_bounds__(kBlock) void k_combine(const double *partial, size_t n_values, uint32_t chunks, double *accum) {
+// a pixel's slots added in sample order, then to the image
+__global__ __launch_bounds__(kBlock) void k_combine(const double *slots, size_t n_values, uint32_t samples, double *accum) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_values) return;
     double sum = 0;
-    for (uint32_t c = 0; c < chunks; ++c) sum += partial[(size_t)c * n_values + i];
+    for (uint32_t s = 0; s < samples; ++s) sum += slots[(size_t)s * n_values + i];
     accum[i] += sum;
 }
 
@@ -254,8 +267,8 @@ struct on_scene {
     dev_buf<uint8_t> pixels;
     dev_buf<on_perlin_desc> perlins;
     dev_buf<unsigned long long> counter;
-    dev_buf<double> partial;            // chunk sums of frames rendered in several chunks per pixel (see k_render)
-    size_t partial_capacity = 0;
+    dev_buf<double> slots;              // the colours of a window's samples, [sample][pixel][3] (see k_render)
+    size_t slot_capacity = 0;
     int n_cus = 256;
     uint32_t n_objects = 0, n_textures = 0;
     std::vector<char> media_below, plain, walkable;   // per object
@@ -491,25 +504,50 @@ int on_render(on_scene *scene, const on_camera *camera, const on_render_params *
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, stream));
     }
-    const uint32_t tiles = ((camera->image_width + 15u) / 16u) * ((camera->image_height + 15u) / 16u);
-    // One lane per pixel fills the GPU only when the image is large: a frame of fewer pixels cuts every pixel's
-    // samples into chunks (at least four samples each) until there are about 8192 lanes per CU.
     const uint32_t spp = params->sample_end - params->sample_begin;
     const size_t n_values = (size_t)camera->image_width * camera->image_height * 3;
-    uint32_t chunks = 1;
     {
-        const uint64_t lanes = (uint64_t)tiles * kBlock, wanted = (uint64_t)scene->n_cus * 8192;
-        if (lanes < wanted && spp >= 8) chunks = (uint32_t)std::min<uint64_t>((wanted + lanes - 1) / lanes, spp / 4);
-        if (const char *e = getenv("ONNA_CHUNKS")) chunks = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::max(1u, spp)));   // (tests, A/B)
+        // The samples go through in windows of as many as the slot buffer holds (1 GiB: all of them for frames up to
+        // about 440 000 pixels x 100 samples), each window added to the image in sample order by k_combine.
+        const uint32_t tiles8 = ((camera->image_width + 7u) / 8u) * ((camera->image_height + 7u) / 8u);
+        uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, (kSlotBudgetBytes / sizeof(double)) / n_values));
+        if (const char *e = getenv("ONNA_WINDOW")) window = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::max(1u, spp)));   // (tests)
+        if (spp && scene->slot_capacity < n_values * window) {   // (grown on demand; the allocation may synchronise the device)
+            if (scene->slots.p) { (void)hipFree(scene->slots.p); scene->slots.p = nullptr; scene->slot_capacity = 0; }
+            HIP_TRY(scene->slots.alloc(n_values * window));
+            scene->slot_capacity = n_values * window;
+        }
+        for (uint32_t w0 = params->sample_begin; w0 < params->sample_end;) {
+            const uint32_t most = std::min(window, params->sample_end - w0);
+            // A wave takes a run of the window's samples.  Long runs keep the lanes busy (a wave idles for about one path at its
+            // end, whatever its length); short ones at the end of the launch -- blocks start in index order -- keep the tail
+            // short: each run takes a share of what is left, down to kShortestRun samples.  A frame of few tiles cannot afford
+            // long runs at all -- its dearest tile's run would outlast everything else -- so a run is at most 1/8 of a wave
+            // slot's share of the window.  (A window that would need more than kMaxRuns runs ends early.)
+            const uint64_t slots_for_waves = (uint64_t)scene->n_cus * 12;
+            const uint32_t longest = (uint32_t)std::max<uint64_t>(kShortestRun, std::min<uint64_t>(64, (uint64_t)most * tiles8 / (slots_for_waves * 8)));
+            const char *forced = getenv("ONNA_RUNS");   // (tests, A/B) "40,25,15,...": the last length repeats
+            SampleRuns runs;
+            runs.n = 0; runs.start[0] = 0;
+            uint32_t forced_len = 1;
+            for (uint32_t left = most; left && runs.n < kMaxRuns;) {
+                uint32_t len = std::min(longest, std::max(kShortestRun, (uint32_t)(((uint64_t)left * kRunShare + 99) / 100)));
+                if (forced) {
+                    if (*forced) { forced_len = (uint32_t)std::max(1l, strtol(forced, const_cast<char **>(&forced), 10)); if (*forced == ',') ++forced; }
+                    len = forced_len;
+                }
+                len = std::min(len, left);
+                runs.start[runs.n + 1] = runs.start[runs.n] + len;
+                ++runs.n;
+                left -= len;
+            }
+            const uint32_t w1 = w0 + runs.start[runs.n];
+            hipLaunchKernelGGL(k_render, dim3(tiles8 * runs.n), dim3(64), 0, stream, scene->d, *camera, w0, runs, params->seed, scene->slots.p,
+                               scene->counter.p);
+            hipLaunchKernelGGL(k_combine, dim3(grid_for(n_values)), dim3(kBlock), 0, stream, scene->slots.p, n_values, w1 - w0, accum_dev);
+            w0 = w1;
+        }
     }
-    if (chunks > 1 && scene->partial_capacity < n_values * chunks) {   // (grown on demand; the allocation may synchronise the device)
-        if (scene->partial.p) { (void)hipFree(scene->partial.p); scene->partial.p = nullptr; scene->partial_capacity = 0; }
-        HIP_TRY(scene->partial.alloc(n_values * chunks));
-        scene->partial_capacity = n_values * chunks;
-    }
-    hipLaunchKernelGGL(k_render, dim3(tiles * chunks), dim3(kBlock), 0, stream, scene->d, *camera, params->sample_begin, params->sample_end, chunks, params->seed,
-                       accum_dev, scene->partial.p, scene->counter.p);
-    if (chunks > 1) hipLaunchKernelGGL(k_combine, dim3(grid_for(n_values)), dim3(kBlock), 0, stream, scene->partial.p, n_values, chunks, accum_dev);
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(ev.b, stream));

@@ -174,6 +174,31 @@ def test_sample_ranges_add_up_and_frames_repeat():
     s.close()
 
 
+def test_frames_do_not_depend_on_how_the_samples_are_dealt_out(monkeypatch):
+    # A wave takes a run of samples of its 8x8 pixels and its lanes share the run's paths; every path's colour has its own
+    # slot and a pixel's slots are added in sample order.  However the runs are cut, the frame and the count are the same.
+    t = on.Tables("cornell-smoke")
+    s = on.Scene(t)
+    cam = t.camera(width=44, spp=16, depth=10)   # 44 x 44: tiles that reach beyond the image's edge
+    plain, st_plain = s.render(cam, seed=9)
+    for runs in ("1", "16", "7,3", "5,4,3,2,1"):
+        monkeypatch.setenv("ONNA_RUNS", runs)
+        got, st = s.render(cam, seed=9)
+        assert np.array_equal(got, plain), runs
+        assert st.rays == st_plain.rays and st.paths == st_plain.paths == 44 * 44 * 16
+    monkeypatch.delenv("ONNA_RUNS")
+    # more samples than the slot buffer holds go through in passes, each pass's sum added to the image in turn
+    monkeypatch.setenv("ONNA_WINDOW", "5")
+    passes, st = s.render(cam, seed=9)
+    monkeypatch.delenv("ONNA_WINDOW")
+    by_hand = np.zeros_like(plain)
+    for a in range(0, 16, 5):
+        by_hand = by_hand + s.render(cam, seed=9, s_begin=a, s_end=min(16, a + 5))[0]
+    assert np.array_equal(passes, by_hand) and st.rays == st_plain.rays
+    assert np.allclose(passes, plain, rtol=1e-13, atol=1e-15) and plain.any()
+    s.close()
+
+
 def test_sampling_the_lights_changes_the_noise_not_the_picture():
     t = on.Tables("cornell-box")
     cam = t.camera(width=32, spp=1024, depth=20)
