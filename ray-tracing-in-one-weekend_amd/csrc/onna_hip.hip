@@ -23,7 +23,14 @@ using namespace ond;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kShortestRun = 4, kRunShare = 35;   // k_render's runs of samples: each 35 % of what is left, at least 4
+// k_render's runs of samples: each takes 35 % of what is left of its window, at least 4 samples and at most `longest`
+constexpr uint32_t kShortestRun = 4, kRunShare = 35;
+__host__ __device__ inline uint32_t run_length(uint32_t left, uint32_t longest) {
+    uint32_t len = (uint32_t)(((unsigned long long)left * kRunShare + 99) / 100);
+    if (len < kShortestRun) len = kShortestRun;
+    if (len > longest) len = longest;
+    return len < left ? len : left;
+}
 constexpr size_t kSlotBudgetBytes = (size_t)1 << 30;   // of a scene's buffer of per-sample colours (see k_render)
 
 __device__ __forceinline__ Ray load_ray(const rt_ray *r) {
@@ -81,15 +88,27 @@ constexpr uint32_t kMaxRuns = 30;
 // which lane traced what, and when, is not in the result.
 // (163 vector registers: three waves per SIMD.  The walk waits on its own loads, so occupancy is what its speed hangs on:
 // changes that push the count past 168 -- two waves -- have cost 20-30 % whatever else they did.)
-struct SampleRuns { uint32_t n; uint32_t start[kMaxRuns + 1]; };   // run r of a window is its samples [start[r], start[r + 1])
-__global__ __launch_bounds__(64) void k_render(DScene sc, on_camera cam, uint32_t w_begin, SampleRuns runs, uint64_t seed,
+// run r of a window is its samples [start[r], start[r + 1]); n = 0: the runs follow run_length (the default; the table is for tests)
+struct SampleRuns { uint32_t n; uint32_t start[kMaxRuns + 1]; };
+__global__ __launch_bounds__(64) void k_render(DScene sc, on_camera cam, uint32_t w_begin, uint32_t w_len, uint32_t longest, SampleRuns runs, uint64_t seed,
                                                       double *slots, unsigned long long *counters) {
     __shared__ int32_t stacks[kStackCap * 64];
     const uint32_t lane = threadIdx.x;
     const uint32_t tiles_x = (cam.image_width + 7u) / 8u, tiles = tiles_x * ((cam.image_height + 7u) / 8u);
     const uint32_t tile = blockIdx.x % tiles, part = blockIdx.x / tiles;
     const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
-    const uint32_t s0 = w_begin + runs.start[part], s1 = w_begin + runs.start[part + 1];
+    uint32_t s0, s1;
+    if (runs.n) {
+        s0 = w_begin + runs.start[part]; s1 = w_begin + runs.start[part + 1];
+    } else {   // (the same for the whole wave: a few scalar operations per run before this one)
+        uint32_t start = 0, left = w_len, len;
+        for (uint32_t i = 0;; ++i) {
+            len = run_length(left, longest);
+            if (i == part) break;
+            start += len; left -= len;
+        }
+        s0 = w_begin + start; s1 = s0 + len;
+    }
     const uint32_t n_paths = 64u * (s1 - s0);
     const size_t n_values = (size_t)cam.image_width * cam.image_height * 3;
     const LaneStack st = {stacks + lane, 64};
@@ -523,26 +542,28 @@ int on_render(on_scene *scene, const on_camera *camera, const on_render_params *
             // end, whatever its length); short ones at the end of the launch -- blocks start in index order -- keep the tail
             // short: each run takes a share of what is left, down to kShortestRun samples.  A frame of few tiles cannot afford
             // long runs at all -- its dearest tile's run would outlast everything else -- so a run is at most 1/8 of a wave
-            // slot's share of the window.  (A window that would need more than kMaxRuns runs ends early.)
+            // slot's share of the window.
             const uint64_t slots_for_waves = (uint64_t)scene->n_cus * 12;
             const uint32_t longest = (uint32_t)std::max<uint64_t>(kShortestRun, std::min<uint64_t>(64, (uint64_t)most * tiles8 / (slots_for_waves * 8)));
-            const char *forced = getenv("ONNA_RUNS");   // (tests, A/B) "40,25,15,...": the last length repeats
+            const char *forced = getenv("ONNA_RUNS");   // (tests, A/B) "40,25,15,...": the last length repeats; at most kMaxRuns runs a pass
             SampleRuns runs;
             runs.n = 0; runs.start[0] = 0;
-            uint32_t forced_len = 1;
-            for (uint32_t left = most; left && runs.n < kMaxRuns;) {
-                uint32_t len = std::min(longest, std::max(kShortestRun, (uint32_t)(((uint64_t)left * kRunShare + 99) / 100)));
-                if (forced) {
-                    if (*forced) { forced_len = (uint32_t)std::max(1l, strtol(forced, const_cast<char **>(&forced), 10)); if (*forced == ',') ++forced; }
-                    len = forced_len;
+            uint32_t n_runs = 0, covered = most;
+            if (forced) {
+                uint32_t len = 1;
+                for (uint32_t left = most; left && runs.n < kMaxRuns;) {
+                    if (*forced) { len = (uint32_t)std::max(1l, strtol(forced, const_cast<char **>(&forced), 10)); if (*forced == ',') ++forced; }
+                    const uint32_t take = std::min(len, left);
+                    runs.start[runs.n + 1] = runs.start[runs.n] + take;
+                    ++runs.n;
+                    left -= take;
                 }
-                len = std::min(len, left);
-                runs.start[runs.n + 1] = runs.start[runs.n] + len;
-                ++runs.n;
-                left -= len;
+                n_runs = runs.n; covered = runs.start[runs.n];
+            } else {
+                for (uint32_t left = most; left; ++n_runs) left -= run_length(left, longest);
             }
-            const uint32_t w1 = w0 + runs.start[runs.n];
-            hipLaunchKernelGGL(k_render, dim3(tiles8 * runs.n), dim3(64), 0, stream, scene->d, *camera, w0, runs, params->seed, scene->slots.p,
+            const uint32_t w1 = w0 + covered;
+            hipLaunchKernelGGL(k_render, dim3(tiles8 * n_runs), dim3(64), 0, stream, scene->d, *camera, w0, covered, longest, runs, params->seed, scene->slots.p,
                                scene->counter.p);
             hipLaunchKernelGGL(k_combine, dim3(grid_for(n_values)), dim3(kBlock), 0, stream, scene->slots.p, n_values, w1 - w0, accum_dev);
             w0 = w1;

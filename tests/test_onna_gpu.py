@@ -196,6 +196,13 @@ def test_frames_do_not_depend_on_how_the_samples_are_dealt_out(monkeypatch):
         by_hand = by_hand + s.render(cam, seed=9, s_begin=a, s_end=min(16, a + 5))[0]
     assert np.array_equal(passes, by_hand) and st.rays == st_plain.rays
     assert np.allclose(passes, plain, rtol=1e-13, atol=1e-15) and plain.any()
+    # a small frame with many samples: dozens of short runs by the default rule against one run of them all
+    cam = t.camera(width=16, spp=256, depth=6)
+    many, st_many = s.render(cam, seed=2)
+    monkeypatch.setenv("ONNA_RUNS", "256")
+    one, st_one = s.render(cam, seed=2)
+    monkeypatch.delenv("ONNA_RUNS")
+    assert np.array_equal(many, one) and st_many.rays == st_one.rays and many.any()
     s.close()
 
 
