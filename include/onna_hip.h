@@ -127,7 +127,7 @@ int on_pdf_value_batch(on_scene *scene, int32_t object, const double *od, size_t
  * order and that sum is added to accum_dev -- so the frame does not depend on how the work was
  * scheduled, and disjoint sample ranges add up to the whole frame's sums (a rounding per range
  * apart).  The slots live in a buffer of the scene's (image_height * image_width * 3 doubles per
- * sample, at most 1 GiB; allocated or grown by the first call that needs it, which may synchronise
+ * sample, at most 4 GiB; allocated or grown by the first call that needs it, which may synchronise
  * the device); calls with more samples than it holds go through in several passes, each pass's
  * sum added to accum_dev in turn.  Renders of ONE scene must not overlap
  * in time.  stats may be NULL; when given, the call waits for the frame and fills it. */

@@ -31,7 +31,7 @@ __host__ __device__ inline uint32_t run_length(uint32_t left, uint32_t longest) 
     if (len > longest) len = longest;
     return len < left ? len : left;
 }
-constexpr size_t kSlotBudgetBytes = (size_t)1 << 30;   // of a scene's buffer of per-sample colours (see k_render)
+constexpr size_t kSlotBudgetBytes = (size_t)4 << 30;   // of a scene's buffer of per-sample colours (see k_render)
 
 __device__ __forceinline__ Ray load_ray(const rt_ray *r) {
     Ray o;
@@ -526,8 +526,8 @@ int on_render(on_scene *scene, const on_camera *camera, const on_render_params *
     const uint32_t spp = params->sample_end - params->sample_begin;
     const size_t n_values = (size_t)camera->image_width * camera->image_height * 3;
     {
-        // The samples go through in windows of as many as the slot buffer holds (1 GiB: all of them for frames up to
-        // about 440 000 pixels x 100 samples), each window added to the image in sample order by k_combine.
+        // The samples go through in windows of as many as the slot buffer holds (4 GiB: all of them for frames up to
+        // about 1.7 million pixels x 100 samples), each window added to the image in sample order by k_combine.
         const uint32_t tiles8 = ((camera->image_width + 7u) / 8u) * ((camera->image_height + 7u) / 8u);
         uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, (kSlotBudgetBytes / sizeof(double)) / n_values));
         if (const char *e = getenv("ONNA_WINDOW")) window = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::max(1u, spp)));   // (tests)
