@@ -158,6 +158,20 @@ def test_frames_match_the_checker(name, earth_png):
     s.close()
 
 
+def test_a_larger_frame_matches_the_checker():
+    # 225 tiles of 8x8 pixels, the last row and column of them ragged, several runs of samples per tile
+    t = on.Tables("cornell-smoke")
+    s = on.Scene(t)
+    cam = t.camera(width=117, spp=16, depth=20)
+    got, stats = s.render(cam, seed=21)
+    exp, c = oo.render(t, cam, seed=21)
+    assert stats.paths == c.paths == 117 * 117 * 16
+    assert abs(int(stats.rays) - int(c.rays)) <= 4   # (media: a free path within an ulp of the boundary)
+    close = np.isclose(got, exp, rtol=1e-11, atol=1e-13)
+    assert close.mean() > 0.999, (~close).sum()
+    s.close()
+
+
 def test_sample_ranges_add_up_and_frames_repeat():
     t = on.Tables("cornell-box")
     s = on.Scene(t)
