@@ -396,7 +396,7 @@ def onna_configs(device):
                 s.render_device(cam, params, accum.data_ptr(), stream, st)
                 ms.append(st.kernel_ms)
             rec = {"config": f"onna {name}: {cam.image_width}x{cam.image_height}, 100 stratified samples, depth 50, f64 sums", "scene": name,
-                   "value": st.paths / np.mean(ms) / 1e3, "unit": "Mpaths/s", "kernel_ms_steps": ms, "rays_per_path": st.rays / st.paths,
+                   "value": st.paths / np.mean(ms) / 1e3, "unit": "Mpaths/s", "ms_per_step": float(np.mean(ms)), "kernel_ms_steps": ms, "rays_per_path": st.rays / st.paths,
                    "mean_radiance": float(accum.mean().item()) / 300, "parity": "checker unpinned (no Lisp here); GPU == checker in tests/test_onna_gpu.py"}
             # the checker on one host core over a small frame of the same scene and camera: the CPU figure, and the
             # counts of the Lisp traversal (box, sphere and quad tests per ray) for the algorithmic flops per path
