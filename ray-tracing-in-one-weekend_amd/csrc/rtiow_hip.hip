@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
     double *const rcp_size = reinterpret_cast<double *>(lds_raw + kCameraLds + 48);
     if (tid == 0) { rcp_size[0] = refined_rcp((double)nx); rcp_size[1] = refined_rcp((double)ny); }
     uint32_t *const ring_tile = reinterpret_cast<uint32_t *>(lds_raw + kCameraLds + 64) + wave * 4;   // the tile in each of this wave's ring entries
+    uint32_t *const strips_done = reinterpret_cast<uint32_t *>(lds_raw + kCameraLds + 44);            // bit q: the queue of strip q is used up
+    if (tid == 0) *strips_done = 0;
     __syncthreads();
     // a tile is 8x8 or 4x4 pixels (tile_shift 3 or 2)
     const uint32_t tile_side = 1u << tile_shift, tile_px = tile_side * tile_side;
@@ -364,17 +366,23 @@ __global__ __launch_bounds__(256 * WAVES) void k_render(DScene sc, DCamera cam_a
                 if (lane == 0) {
                     if (regions > 1) {
                         // A tree in device memory: the frame is cut into vertical strips, one per XCD, each with its own
-                        // queue (dearest tile first), so that the nodes a strip's rays visit gather in that XCD's L2
+                        // queue, so that the nodes a strip's rays visit gather in that XCD's L2
                         // instead of every L2 holding a thin slice of everything.  Blocks are dealt to the XCDs in turn
                         // (block b runs on XCD b % 8); a block whose strip is used up helps with the next ones.
-                        const uint32_t *seg = tile_order + n_tiles;   // where each strip starts in the order, and n_tiles last
+                        // (an ordered frame's strips are listed behind the order, dearest tile first; otherwise a strip's tiles go row
+                        // by row.  A strip found used up is marked in LDS, so that the block does not ask its counter again.)
+                        const uint32_t *seg = tile_order ? tile_order + n_tiles : nullptr;   // where each strip starts in the order, and n_tiles last
                         tile = n_tiles;
+                        const uint32_t used_up = *strips_done;
                         uint32_t q = blockIdx.x % regions;
                         for (uint32_t tries = 0; tries < regions; ++tries, q = q + 1 == regions ? 0 : q + 1) {
-                            const uint32_t len = seg[q + 1] - seg[q];
-                            if (__hip_atomic_load(counters + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+                            if ((used_up >> q) & 1u) continue;
+                            const uint32_t x0 = strip_begin(q, tiles_x, regions), width = strip_begin(q + 1, tiles_x, regions) - x0;
+                            const uint32_t from = seg ? seg[q] : 0u;
+                            const uint32_t len = seg ? seg[q + 1] - from : width * tiles_y;
                             const uint32_t pos = (uint32_t)atomicAdd(counters + 4 + q, 1ull);
-                            if (pos < len) { tile = tile_order[seg[q] + pos]; break; }
+                            if (pos < len) { tile = seg ? tile_order[from + pos] : (pos / width) * tiles_x + x0 + pos % width; break; }
+                            atomicOr(strips_done, 1u << q);
                         }
                     } else {
                         tile = (uint32_t)atomicAdd(counters + 1, 1ull);
@@ -1837,10 +1845,9 @@ static frame_plan plan_frame(const rt_scene *scene, const rt_render_params *pr) 
     // the pass traces 1 to 4 samples per pixel without touching the image, under 2 % of the work.
     f.ordered = spp >= kOrderMinSamples && f.n_tiles >= 2 * f.blocks * f.waves && !getenv("RTIOW_TILE_ORDER_OFF");
     // a tree in device memory: the tiles of each of eight vertical strips go to the blocks of one XCD first
-    // (cost-ordered frames only: with the tiles handed out in image order -- frames under kOrderMinSamples samples, the costing
-    // pass -- strips measured slower, 8.3 against 7.2 ms for 8 samples of 10^6 spheres, and no different for the costing pass)
-    f.regions = f.ordered && !scene->render_lds_tree && f.tiles_x >= 4 * kRegions && f.blocks >= kRegions ? kRegions : 1u;
-    if (const char *e = getenv("RTIOW_TILE_REGIONS")) f.regions = f.ordered && atoi(e) > 1 && f.tiles_x >= kRegions ? kRegions : 1u;   // (A/B, tests)
+    // (at least 64 tile columns, so that the costing pass's 8x8 tiles make strips too)
+    f.regions = !scene->render_lds_tree && f.tiles_x >= 8 * kRegions && f.blocks >= kRegions ? kRegions : 1u;
+    if (const char *e = getenv("RTIOW_TILE_REGIONS")) f.regions = atoi(e) > 1 && f.tiles_x >= 2 * kRegions ? kRegions : 1u;   // (A/B, tests)
     return f;
 }
 
@@ -1865,7 +1872,7 @@ static int launch_frame(rt_scene *scene, const rt_camera *camera, const rt_rende
     hipLaunchKernelGGL((k_render<T, L, W, C, D, X>), grid, block, scene->render_lds_bytes, stream, dsc, cam, pr->nx, pr->ny,   \
                        s_from, S_END, pr->max_depth, pr->t_min, pr->seed, (T *)(ACCUM), COUNTERS,                           \
                        scene->render_lnodes, scene->render_lleaves, scene->render_stack_cap, mem.spill, ORDER, COST, SHIFT, \
-                       scene->render_sums_per_wave, (ORDER) ? regions : 1u)
+                       scene->render_sums_per_wave, regions)
 #define RT_LAUNCH_TREE(T, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT)                                                      \
     do {                                                                                                                  \
         if (!scene->render_lds_tree) RT_LAUNCH(T, false, kWavesMax, C, D, S_END, ACCUM, COUNTERS, ORDER, COST, SHIFT);               \
