@@ -762,6 +762,14 @@ def test_cost_ordered_tiles_render_the_same_frame(rt, worlds, monkeypatch):
         monkeypatch.delenv("RTIOW_TILE_REGIONS")
         assert s_strips.rays == s_single.rays and s_strips.paths == 800 * 640 * 32
         assert np.array_equal(strips, single) and strips.any() and not np.array_equal(strips, ordered)
+        # ... also for a frame of few samples, whose tiles are not ordered by cost (a strip's tiles then go row by row)
+        monkeypatch.setenv("RTIOW_TILE_REGIONS", "8")
+        strips, s_strips = w.render(rt.camera(cam15), 800, 640, 2, 2 + 6, 9, accum)
+        monkeypatch.setenv("RTIOW_TILE_REGIONS", "1")
+        single, s_single = w.render(rt.camera(cam15), 800, 640, 2, 2 + 6, 9, accum)
+        monkeypatch.delenv("RTIOW_TILE_REGIONS")
+        assert s_strips.rays == s_single.rays and s_strips.paths == 800 * 640 * 6
+        assert np.array_equal(strips, single) and strips.any()
 
 
 EDGE_FRAMES = [
