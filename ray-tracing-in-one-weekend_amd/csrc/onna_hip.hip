@@ -86,7 +86,7 @@ constexpr uint32_t kMaxRuns = 30;
 // at the wave's end is one path.  A path's colour goes to its own slot, slots[sample - w_begin][pixel][3], and k_combine adds
 // a pixel's slots in sample order (blend-colours sums a pixel's samples in the order they were collected: colour.lisp:20-29):
 // which lane traced what, and when, is not in the result.
-// (163 vector registers: three waves per SIMD.  The walk waits on its own loads, so occupancy is what its speed hangs on:
+// (161 vector registers: three waves per SIMD.  The walk waits on its own loads, so occupancy is what its speed hangs on:
 // changes that push the count past 168 -- two waves -- have cost 20-30 % whatever else they did.)
 // run r of a window is its samples [start[r], start[r + 1]); n = 0: the runs follow run_length (the default; the table is for tests)
 struct SampleRuns { uint32_t n; uint32_t start[kMaxRuns + 1]; };
